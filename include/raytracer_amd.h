@@ -1,0 +1,243 @@
+/*
+ * raytracer_amd.h — C-ABI of the MI355X (gfx950) backend for the per-pixel tracing loop of
+ * matteoilardi/Raytracer.
+ *
+ * The reference has no plugin / FFI layer.  The seam this library sits behind is the single call
+ *
+ *     tracer.fire_all_rays([&renderer](const Ray &r) { return (*renderer)(r); }, show_progress);
+ *                                                           (reference src/raytracer.cpp:151-153)
+ *
+ * on an ImageTracer built at src/raytracer.cpp:140-144 with a Renderer from build_renderer
+ * (src/raytracer.cpp:147,333-356).  A per-ray std::function cannot be GPU-backed, so the backend
+ * replaces the whole fire_all_rays call and keeps its post-condition: HdrImage::pixels filled,
+ * W*H Color (3 x f32), row-major, row 0 = top (include/colors.hpp:448-464).
+ *
+ * Everything here is plain C: pointers, sizes and PODs.  No torch / HIP types in the signatures
+ * (a hipStream_t travels as void*).  Every entry point returns rt_status; rt_last_error() gives the
+ * thread-local message of the last failing call.  No exception crosses this boundary.
+ *
+ * Matrices: a "hom matrix" is 12 floats = the 3x3 linear part row-major followed by the translation
+ * vector, exactly HomMatrix::linear_part / HomMatrix::translation_vec (include/geometry.hpp:332-333).
+ * The flattener copies Transformation::hom_matrix ("fwd") and Transformation::inverse_hom_matrix
+ * ("inv") verbatim (include/geometry.hpp:437-438) — the library never re-inverts.
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = 1, /* bad sizes / indices / enum values / limits exceeded           */
+  RT_ERR_HIP = 2,              /* a HIP runtime call failed (message carries hipGetErrorString) */
+  RT_ERR_NO_DEVICE = 3,        /* no gfx950 device visible                                      */
+  RT_ERR_OUT_OF_MEMORY = 4
+} rt_status;
+
+/* Sphere / Plane: include/shapes.hpp:193,309 */
+enum { RT_SHAPE_SPHERE = 0, RT_SHAPE_PLANE = 1 };
+/* CSGObject::Operation: include/shapes.hpp:380 (same order) */
+enum { RT_CSG_UNION = 0, RT_CSG_INTERSECTION = 1, RT_CSG_DIFFERENCE = 2, RT_CSG_FUSION = 3 };
+/* DiffusiveBRDF / SpecularBRDF: include/materials.hpp:180,219 */
+enum { RT_BRDF_DIFFUSE = 0, RT_BRDF_SPECULAR = 1 };
+/* UniformPigment / CheckeredPigment / ImagePigment: include/materials.hpp:50,72,102 */
+enum { RT_PIGMENT_UNIFORM = 0, RT_PIGMENT_CHECKERED = 1, RT_PIGMENT_IMAGE = 2 };
+/* OrthogonalCamera / PerspectiveCamera: include/cameras.hpp:124,140 */
+enum { RT_CAMERA_ORTHOGONAL = 0, RT_CAMERA_PERSPECTIVE = 1 };
+/* ModeCfg::Mode: src/raytracer.cpp:48 (--mode onoff|flat|pointlight|path) */
+enum { RT_MODE_ONOFF = 0, RT_MODE_FLAT = 1, RT_MODE_POINTLIGHT = 2, RT_MODE_PATH = 3 };
+/* How path mode consumes random numbers (see rt_render_cfg::rng_mode) */
+enum { RT_RNG_PER_SAMPLE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
+
+/* Limits of the device CSG evaluator (fixed-capacity, no heap). */
+#define RT_MAX_CSG_DEPTH 8    /* nesting depth of CSG nodes below one top-level object */
+#define RT_MAX_CSG_LEAVES 32  /* Sphere/Plane leaves below one top-level CSG object    */
+
+/*
+ * Object reference used by `objects`, `csg_left`, `csg_right`:
+ *   ref >= 0 : index into the shape arrays
+ *   ref <  0 : CSG node index = ~ref  (i.e. -ref-1)
+ */
+typedef int32_t rt_ref;
+
+/*
+ * Flattened World (include/shapes.hpp:520-527) + the Materials its Shapes point to
+ * (include/shapes.hpp:140, include/scenefiles.hpp:553).  Struct-of-arrays; the caller owns every
+ * array, rt_scene_create copies them to the device.
+ */
+typedef struct rt_scene_desc {
+  /* Shapes (top-level and CSG leaves alike) */
+  uint32_t n_shapes;
+  const uint8_t *shape_kind;      /* [n_shapes] RT_SHAPE_*                                   */
+  const uint32_t *shape_material; /* [n_shapes] index into the material arrays               */
+  const float *shape_fwd;         /* [n_shapes][12] Object::transformation.hom_matrix         */
+  const float *shape_inv;         /* [n_shapes][12] Object::transformation.inverse_hom_matrix */
+
+  /* CSG nodes (include/shapes.hpp:374-391) */
+  uint32_t n_csg_nodes;
+  const uint8_t *csg_op;    /* [n_csg_nodes] RT_CSG_*      */
+  const rt_ref *csg_left;   /* [n_csg_nodes] object1       */
+  const rt_ref *csg_right;  /* [n_csg_nodes] object2       */
+  const float *csg_fwd;     /* [n_csg_nodes][12]           */
+  const float *csg_inv;     /* [n_csg_nodes][12]           */
+
+  /* World::objects in insertion order (ties in closest-hit go to the lowest index,
+   * include/shapes.hpp:556) */
+  uint32_t n_objects;
+  const rt_ref *objects; /* [n_objects] */
+
+  /* Materials (include/materials.hpp:269-286) */
+  uint32_t n_materials;
+  const uint8_t *material_brdf;              /* [n_materials] RT_BRDF_*           */
+  const uint32_t *material_brdf_pigment;     /* [n_materials] index into pigments */
+  const uint32_t *material_emission_pigment; /* [n_materials] index into pigments */
+
+  /* Pigments (include/materials.hpp:39-138) */
+  uint32_t n_pigments;
+  const uint8_t *pigment_kind;        /* [n_pigments] RT_PIGMENT_*                            */
+  const float *pigment_color1;        /* [n_pigments][3] uniform colour / checkered colour 1  */
+  const float *pigment_color2;        /* [n_pigments][3] checkered colour 2                   */
+  const int32_t *pigment_n_intervals; /* [n_pigments] checkered only                          */
+  const uint32_t *pigment_tex_offset; /* [n_pigments] image only: first texel in `texels`     */
+  const int32_t *pigment_tex_width;   /* [n_pigments] image only                              */
+  const int32_t *pigment_tex_height;  /* [n_pigments] image only                              */
+
+  /* Texture pool for ImagePigment: HdrImage::pixels row-major, 3 floats per texel */
+  uint32_t n_texels;
+  const float *texels; /* [n_texels][3] */
+
+  /* World::light_sources (include/shapes.hpp:498-513) */
+  uint32_t n_lights;
+  const float *light_point;  /* [n_lights][3] */
+  const float *light_color;  /* [n_lights][3] */
+  const float *light_radius; /* [n_lights] emission_radius */
+} rt_scene_desc;
+
+/* Camera (include/cameras.hpp:73-160) */
+typedef struct rt_camera {
+  uint32_t kind;         /* RT_CAMERA_*                                                        */
+  float fwd[12];         /* Camera::transformation.hom_matrix                                  */
+  float asp_ratio;       /* used iff has_asp_ratio != 0                                        */
+  uint32_t has_asp_ratio;/* 0: asp = float(width)/float(height) (include/cameras.hpp:184-186)  */
+  float distance;        /* PerspectiveCamera::distance                                        */
+} rt_camera;
+
+/*
+ * Render configuration = ImgSize + ModeCfg + PathCfg (src/raytracer.cpp:35-51) + the constants
+ * build_renderer passes (src/raytracer.cpp:337,348,352) + the row sharding of the image.
+ */
+typedef struct rt_render_cfg {
+  int32_t width, height;   /* full image size                                                   */
+  int32_t spp_edge;        /* --antialiasing: samples per pixel edge                            */
+  uint32_t mode;           /* RT_MODE_*                                                         */
+  int32_t n_rays;          /* --n_rays                                                          */
+  int32_t roulette;        /* --roulette                                                        */
+  int32_t max_depth;       /* --max-depth                                                       */
+  uint64_t seq_number;     /* --seq-number: path PCG stream = PCG(42, seq_number)               */
+  float background[3];     /* Renderer::background_color                                        */
+  float ambient[3];        /* PointLightTracer::ambient_color                                   */
+  /*
+   * The reference's PointLightTracer mirror loop has no bounce cap and can spin forever
+   * (include/renderers.hpp:129-152).  A lane must never spin: after this many specular bounces
+   * the sample returns background*attenuation-so-far and is counted in rt_stats.capped_samples.
+   */
+  int32_t max_mirror_bounces;
+  /*
+   * RT_RNG_PER_SAMPLE_STREAMS: every pixel sample owns a PCG stream derived from
+   * (seq_number, global sample index); image independent of GPU count.  Statistical parity.
+   * RT_RNG_SERIAL_REFERENCE is not available on the device (the reference consumes one stream
+   * serially over the whole image); the value exists so that the CPU oracle can be asked for it.
+   */
+  uint32_t rng_mode;
+  /*
+   * Rows this call renders: local row lr in [0, n_local_rows) is image row
+   *     (lr / band_rows) * band_stride + band_offset + lr % band_rows .
+   * Whole image: band_rows = band_stride = height, band_offset = 0, n_local_rows = height.
+   * Rank r of R with 16-row cyclic bands: band_rows = 16, band_stride = 16*R, band_offset = 16*r.
+   */
+  int32_t band_rows, band_stride, band_offset, n_local_rows;
+} rt_render_cfg;
+
+typedef struct rt_stats {
+  uint64_t rays;           /* closest-hit / any-hit / shadow queries (World::ray_intersection &c.) */
+  uint64_t samples;        /* pixel samples traced                                                */
+  uint64_t capped_samples; /* pointlight samples that hit max_mirror_bounces                       */
+  float kernel_ms;         /* trace (+ resolve) kernel time from hipEvents; 0 if !timing            */
+} rt_stats;
+
+/* World::ray_intersection result for rt_trace_rays: HitRecord (include/shapes.hpp:65-96) as POD. */
+typedef struct rt_hit {
+  int32_t object;   /* index into World::objects, -1 = miss                */
+  int32_t shape;    /* shape (leaf) index that was hit                     */
+  float t;
+  float point[3];   /* HitRecord::world_point                              */
+  float normal[3];  /* HitRecord::normal (NOT normalised, as the reference) */
+  float uv[2];      /* HitRecord::surface_point                            */
+} rt_hit;
+
+/* One ray for rt_trace_rays: Ray (include/cameras.hpp:34-41). */
+typedef struct rt_ray {
+  float origin[3];
+  float direction[3];
+  float tmin, tmax;
+} rt_ray;
+
+typedef struct rt_scene rt_scene; /* opaque: device copy of a flattened World */
+
+/* Library / device ------------------------------------------------------------------------------ */
+
+/* Message of the last failing call on this thread ("" if none). Never NULL. */
+const char *rt_last_error(void);
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int rt_device_count(void);
+
+/* Scene -------------------------------------------------------------------------------------------
+ * Replaces: the World the reference hands to build_renderer (src/raytracer.cpp:147) — flattened
+ * once, reused for any number of renders (animation frames change only the camera).
+ * Validates every index / enum / CSG limit; copies the arrays to `device`. */
+rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/* Render ------------------------------------------------------------------------------------------
+ * Replaces: ImageTracer::fire_all_rays (include/cameras.hpp:221-251) driving
+ * OnOffTracer / FlatTracer / PointLightTracer / PathTracer::operator()
+ * (include/renderers.hpp:62,88,121,208).
+ *
+ * rgb_out_device: device pointer on the scene's device, n_local_rows*width*3 floats, row-major,
+ *                 local row 0 first (HdrImage::pixels layout for the rows this call owns).
+ * stream:         hipStream_t as void* (NULL = default stream).  The call enqueues and returns;
+ *                 it synchronises only if `stats` is non-NULL (to read the counters back).
+ */
+rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
+                    float *rgb_out_device, void *stream, rt_stats *stats);
+
+/* Same, into host memory (allocates a device framebuffer, renders, copies back, synchronises).
+ * This is what the C++ adapter for the reference's ImageTracer calls. */
+rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
+                         float *rgb_out_host, rt_stats *stats);
+
+/* Batch closest-hit --------------------------------------------------------------------------------
+ * Replaces: World::ray_intersection (include/shapes.hpp:547-561) for n rays at once; one ray per
+ * lane.  rays / hits are HOST pointers (debug / parity entry point, not a hot path). */
+rt_status rt_trace_rays(rt_scene *scene, const rt_ray *rays, size_t n, rt_hit *hits);
+
+/* Batch shadow test: World::offset_if_visible (include/shapes.hpp:584-603).
+ * viewer/surface/normal: [n][3] host floats; visible[n] receives 1/0. */
+rt_status rt_offset_if_visible(rt_scene *scene, const float *viewer, const float *surface,
+                               const float *normal, size_t n, uint8_t *visible);
+
+/* Antialiasing jitter of sample k: the 2k-th and (2k+1)-th PCG(42,54).random_float()
+ * (include/cameras.hpp:232-233, include/random.hpp:52-70), by LCG jump-ahead on the device.
+ * Host pointers; parity entry point for the exact-jitter claim. */
+rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float *u_out, float *v_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */

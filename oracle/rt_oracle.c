@@ -1,0 +1,864 @@
+/*
+ * rt_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded CPU restatement of the per-pixel tracing loop of matteoilardi/Raytracer
+ * over the flattened scene of include/raytracer_amd.h.  Every function cites the reference
+ * file:line it follows (paths relative to the reference root).  It keeps the reference's structure
+ * (recursive path tracer, recursive CSG hit lists, one serial PCG) and its fp32 operation order,
+ * so that with RT_RNG_SERIAL_REFERENCE it reproduces the reference's images bit for bit on this
+ * image's glibc (pinned by tests/test_oracle_vs_golden.py against fixtures rendered by the
+ * unmodified reference, oracle/_ref/rt_ref, and by the known-answer values restated from the
+ * reference's own test .cpp files in tests/test_oracle_known_answers.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (raytracer_amd/) never does.
+ *
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, like the x86-64 -O2
+ * reference build).
+ */
+#include "raytracer_amd.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define RTO_EXPORT __attribute__((visibility("default")))
+#define MAX_HITS (2 * RT_MAX_CSG_LEAVES)
+
+static const float PI_F = 3.14159265358979323846f; /* std::numbers::pi_v<float> */
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float r, g, b; } col3;
+
+typedef struct {
+  v3 o, d;
+  float tmin, tmax;
+  int depth;
+} ray_t; /* include/cameras.hpp:34-41 */
+
+typedef struct {
+  int shape; /* HitRecord::shape as a shape index */
+  v3 point;  /* world_point */
+  v3 normal;
+  float u, v; /* surface_point */
+  float t;
+} hit_t; /* include/shapes.hpp:65-96 (the `ray` member is never read by any renderer) */
+
+/* ---------------------------------------------------------------------------------------------
+ * Geometry (include/geometry.hpp)
+ * ------------------------------------------------------------------------------------------ */
+
+/* HomMatrix::apply(Vec) — include/geometry.hpp:379-384 */
+static v3 hom_apply_vec(const float *m, v3 v) {
+  v3 r;
+  r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z;
+  r.y = m[3] * v.x + m[4] * v.y + m[5] * v.z;
+  r.z = m[6] * v.x + m[7] * v.y + m[8] * v.z;
+  return r;
+}
+
+/* HomMatrix::apply(Point) — include/geometry.hpp:387-393 */
+static v3 hom_apply_point(const float *m, v3 p) {
+  v3 r;
+  r.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[9];
+  r.y = m[3] * p.x + m[4] * p.y + m[5] * p.z + m[10];
+  r.z = m[6] * p.x + m[7] * p.y + m[8] * p.z + m[11];
+  return r;
+}
+
+/* HomMatrix::apply_transposed(Normal) — include/geometry.hpp:396-400 */
+static v3 hom_apply_transposed(const float *m, v3 n) {
+  v3 r;
+  r.x = m[0] * n.x + m[3] * n.y + m[6] * n.z;
+  r.y = m[1] * n.x + m[4] * n.y + m[7] * n.z;
+  r.z = m[2] * n.x + m[5] * n.y + m[8] * n.z;
+  return r;
+}
+
+static float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* geometry.hpp:263-265 */
+static float sqnorm3(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     /* geometry.hpp:104 */
+static v3 add3(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+static v3 sub3(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static v3 scale3(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }  /* Vec * scalar  */
+static v3 lscale3(float s, v3 a) { v3 r = {s * a.x, s * a.y, s * a.z}; return r; } /* scalar * Vec  */
+
+/* Vec::normalized / Normal::normalized — include/geometry.hpp:111-114, 208-211 */
+static v3 normalized3(v3 a) {
+  float n = sqrtf(sqnorm3(a));
+  v3 r = {a.x / n, a.y / n, a.z / n};
+  return r;
+}
+
+/* are_close — include/colors.hpp:81 */
+static int are_close(float x, float y) { return fabsf(x - y) < 1e-5f; }
+
+/* Point::is_close — include/geometry.hpp:153-156 */
+static int point_is_close(v3 a, v3 b) { return are_close(a.x, b.x) && are_close(a.y, b.y) && are_close(a.z, b.z); }
+
+/* Ray::transform — include/cameras.hpp:66 */
+static ray_t ray_transform(ray_t r, const float *m) {
+  ray_t q = r;
+  q.o = hom_apply_point(m, r.o);
+  q.d = hom_apply_vec(m, r.d);
+  return q;
+}
+
+/* ONB(Vec) (Duff et al.) — include/geometry.hpp:591-599 */
+static void onb_from_e3(v3 e3, v3 *e1, v3 *e2) {
+  float sign = copysignf(1.f, e3.z);
+  const float a = -1.f / (sign + e3.z);
+  const float b = e3.x * e3.y * a;
+  e1->x = 1.f + sign * e3.x * e3.x * a;
+  e1->y = sign * b;
+  e1->z = -sign * e3.x;
+  e2->x = b;
+  e2->y = sign + e3.y * e3.y * a;
+  e2->z = -e3.y;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * PCG — include/random.hpp:29-101
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t state, inc; } pcg_t;
+#define PCG_MULT 6364136223846793005ull
+
+/* PCG::random — include/random.hpp:52-64 */
+static uint32_t pcg_random(pcg_t *p) {
+  uint64_t old = p->state;
+  p->state = old * PCG_MULT + p->inc;
+  uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  uint32_t rot = (uint32_t)(old >> 59u);
+  return (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+}
+
+/* PCG::PCG — include/random.hpp:41-47 */
+static void pcg_init(pcg_t *p, uint64_t init_state, uint64_t init_seq) {
+  p->state = 0;
+  p->inc = (init_seq << 1u) | 1u;
+  pcg_random(p);
+  p->state += init_state;
+  pcg_random(p);
+}
+
+/* PCG::random_float — include/random.hpp:67-70.  std::pow(2.f, 32) is the double 2^32, so the
+ * quotient is float(ran) * 2^-32 exactly; float(ran) rounds to nearest, so 1.0f is reachable. */
+static float pcg_random_float(pcg_t *p) {
+  uint32_t ran = pcg_random(p);
+  return (float)((double)(float)ran / 4294967296.0);
+}
+
+/* LCG jump-ahead (Brown, "Random number generation with arbitrary strides"): advances the state by
+ * n steps in O(log n).  Not in the reference; used to address the AA stream by sample index. */
+static void pcg_advance(pcg_t *p, uint64_t n) {
+  uint64_t acc_mult = 1, acc_plus = 0, cur_mult = PCG_MULT, cur_plus = p->inc;
+  while (n > 0) {
+    if (n & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    n >>= 1;
+  }
+  p->state = acc_mult * p->state + acc_plus;
+}
+
+/* splitmix64 finaliser: derives the per-sample path streams (RT_RNG_PER_SAMPLE_STREAMS).  The
+ * device uses the same derivation (raytracer_amd/csrc/rt_device.h: sample_stream). */
+static uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static void sample_stream(pcg_t *p, uint64_t seq_number, uint64_t global_sample) {
+  uint64_t init_state = mix64(global_sample ^ mix64(seq_number));
+  uint64_t init_seq = mix64(init_state);
+  pcg_init(p, init_state, init_seq);
+}
+
+/* PCG::random_phong — include/random.hpp:75-84 */
+static void pcg_random_phong(pcg_t *p, int n, float *theta, float *phi) {
+  float x = pcg_random_float(p);
+  *theta = acosf(powf(x, 1.f / (float)(n + 1)));
+  *phi = pcg_random_float(p) * 2 * PI_F;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Shapes — include/shapes.hpp
+ * ------------------------------------------------------------------------------------------ */
+typedef const rt_scene_desc S;
+
+/* Sphere::solve_ray_sphere — include/shapes.hpp:269-303.  Returns how many of ts[] are set. */
+static int solve_ray_sphere(ray_t ray, float ts[2]) {
+  v3 O = ray.o;
+  float a = sqnorm3(ray.d);
+  float b = dot3(O, ray.d);
+  float c = sqnorm3(O) - 1.f;
+  float reduced_disc = b * b - a * c;
+  if (reduced_disc <= 0.f)
+    return 0;
+  float t1 = (-b - sqrtf(reduced_disc)) / a;
+  float t2 = (-b + sqrtf(reduced_disc)) / a;
+  if (t1 > t2) {
+    float tmp = t1;
+    t1 = t2;
+    t2 = tmp;
+  }
+  if (t1 < ray.tmin) {
+    if (t2 > ray.tmin && t2 < ray.tmax) {
+      ts[0] = t2;
+      return 1;
+    }
+    return 0;
+  }
+  ts[0] = t1;
+  if (t2 < ray.tmax) {
+    ts[1] = t2;
+    return 2;
+  }
+  return 1;
+}
+
+/* Shape::make_hit + enforce_correct_normal_orientation + calculate_normal/uv —
+ * include/shapes.hpp:163-186, 254-266, 362-367 */
+static hit_t make_hit(S *s, int shape, ray_t ray_local, float t) {
+  hit_t h;
+  v3 p = add3(ray_local.o, lscale3(t, ray_local.d)); /* Ray::at — include/cameras.hpp:62 */
+  v3 n;
+  if (s->shape_kind[shape] == RT_SHAPE_SPHERE) {
+    n = p;
+    float u = atan2f(p.y, p.x) / (2.f * PI_F);
+    if (u < 0.f)
+      u = u + 1.f;
+    h.u = u;
+    h.v = acosf(p.z) / PI_F;
+  } else {
+    n.x = 0.f, n.y = 0.f, n.z = 1.f;
+    h.u = p.x - floorf(p.x);
+    h.v = p.y - floorf(p.y);
+  }
+  float sign = copysignf(1.0f, -(dot3(n, ray_local.d)));
+  n = scale3(n, sign);
+  h.shape = shape;
+  h.t = t;
+  h.point = hom_apply_point(s->shape_fwd + 12 * shape, p);
+  h.normal = hom_apply_transposed(s->shape_inv + 12 * shape, n); /* Transformation * Normal — geometry.hpp:506 */
+  return h;
+}
+
+/* Sphere::ray_intersection / Plane::ray_intersection — include/shapes.hpp:206-221, 322-341 */
+static int shape_ray_intersection(S *s, int shape, ray_t ray_world, hit_t *out) {
+  ray_t ray = ray_transform(ray_world, s->shape_inv + 12 * shape);
+  if (s->shape_kind[shape] == RT_SHAPE_SPHERE) {
+    float ts[2];
+    if (solve_ray_sphere(ray, ts) == 0)
+      return 0;
+    *out = make_hit(s, shape, ray, ts[0]);
+    return 1;
+  }
+  if (are_close(ray.d.z, 0.f))
+    return 0;
+  float t_hit = -ray.o.z / ray.d.z;
+  if (t_hit < ray.tmin || t_hit > ray.tmax)
+    return 0;
+  *out = make_hit(s, shape, ray, t_hit);
+  return 1;
+}
+
+/* Sphere::all_ray_intersections / Plane::all_ray_intersections — include/shapes.hpp:223-242, 343-350 */
+static int shape_all_ray_intersections(S *s, int shape, ray_t ray_world, hit_t *out) {
+  if (s->shape_kind[shape] == RT_SHAPE_PLANE)
+    return shape_ray_intersection(s, shape, ray_world, out);
+  ray_t ray = ray_transform(ray_world, s->shape_inv + 12 * shape);
+  float ts[2];
+  int nt = solve_ray_sphere(ray, ts), n = 0;
+  for (int i = 0; i < nt; ++i)
+    if (ts[i] > ray.tmin && ts[i] < ray.tmax)
+      out[n++] = make_hit(s, shape, ray, ts[i]);
+  return n;
+}
+
+/* Sphere::is_point_inside / Plane::is_point_inside — include/shapes.hpp:245-250, 353-358 */
+static int shape_is_point_inside(S *s, int shape, v3 point_world) {
+  v3 p = hom_apply_point(s->shape_inv + 12 * shape, point_world);
+  if (s->shape_kind[shape] == RT_SHAPE_SPHERE)
+    return sqnorm3(p) < 1.f;
+  return p.z < 0.f;
+}
+
+static int object_is_point_inside(S *s, rt_ref ref, v3 point_world);
+
+/* CSGObject::is_point_inside — include/shapes.hpp:438-457 */
+static int csg_is_point_inside(S *s, int node, v3 point_world) {
+  v3 p = hom_apply_point(s->csg_inv + 12 * node, point_world);
+  const int inside1 = object_is_point_inside(s, s->csg_left[node], p);
+  const int inside2 = object_is_point_inside(s, s->csg_right[node], p);
+  switch (s->csg_op[node]) {
+  case RT_CSG_UNION: return inside1 || inside2;
+  case RT_CSG_INTERSECTION: return inside1 && inside2;
+  case RT_CSG_DIFFERENCE: return inside1 && !inside2;
+  default: return inside1 || inside2; /* FUSION */
+  }
+}
+
+static int object_is_point_inside(S *s, rt_ref ref, v3 point_world) {
+  return ref >= 0 ? shape_is_point_inside(s, ref, point_world) : csg_is_point_inside(s, ~ref, point_world);
+}
+
+/* CSGObject::hit_on_obj1_valid / hit_on_obj2_valid — include/shapes.hpp:460-490 */
+static int hit_on_obj1_valid(S *s, int node, v3 p) {
+  const int inside2 = object_is_point_inside(s, s->csg_right[node], p);
+  switch (s->csg_op[node]) {
+  case RT_CSG_UNION: return 1;
+  case RT_CSG_INTERSECTION: return inside2;
+  default: return !inside2; /* DIFFERENCE, FUSION */
+  }
+}
+static int hit_on_obj2_valid(S *s, int node, v3 p) {
+  const int inside1 = object_is_point_inside(s, s->csg_left[node], p);
+  switch (s->csg_op[node]) {
+  case RT_CSG_UNION: return 1;
+  case RT_CSG_INTERSECTION: return inside1;
+  case RT_CSG_DIFFERENCE: return inside1;
+  default: return !inside1; /* FUSION */
+  }
+}
+
+static int object_all_ray_intersections(S *s, rt_ref ref, ray_t ray_world, hit_t *out);
+
+/* CSGObject::all_ray_intersections + merge_ordered_vectors + HitRecord::transform_in_place —
+ * include/shapes.hpp:405-435, 39-58, 91-95 */
+static int csg_all_ray_intersections(S *s, int node, ray_t ray_world, hit_t *out) {
+  ray_t ray = ray_transform(ray_world, s->csg_inv + 12 * node);
+  hit_t hits1[MAX_HITS], hits2[MAX_HITS];
+  int n1 = object_all_ray_intersections(s, s->csg_left[node], ray, hits1);
+  int n2 = object_all_ray_intersections(s, s->csg_right[node], ray, hits2);
+  int v1 = 0, v2 = 0;
+  for (int i = 0; i < n1; ++i)
+    if (hit_on_obj1_valid(s, node, hits1[i].point))
+      hits1[v1++] = hits1[i];
+  for (int i = 0; i < n2; ++i)
+    if (hit_on_obj2_valid(s, node, hits2[i].point))
+      hits2[v2++] = hits2[i];
+  int i1 = 0, i2 = 0, n = 0;
+  while (i1 < v1 && i2 < v2) {
+    if (hits1[i1].t < hits2[i2].t)
+      out[n++] = hits1[i1++];
+    else
+      out[n++] = hits2[i2++];
+  }
+  while (i1 < v1) out[n++] = hits1[i1++];
+  while (i2 < v2) out[n++] = hits2[i2++];
+  for (int i = 0; i < n; ++i) {
+    out[i].point = hom_apply_point(s->csg_fwd + 12 * node, out[i].point);
+    out[i].normal = hom_apply_transposed(s->csg_inv + 12 * node, out[i].normal);
+  }
+  return n;
+}
+
+static int object_all_ray_intersections(S *s, rt_ref ref, ray_t ray_world, hit_t *out) {
+  return ref >= 0 ? shape_all_ray_intersections(s, ref, ray_world, out)
+                  : csg_all_ray_intersections(s, ~ref, ray_world, out);
+}
+
+/* Object::ray_intersection (CSGObject: include/shapes.hpp:396-401) */
+static int object_ray_intersection(S *s, rt_ref ref, ray_t ray_world, hit_t *out) {
+  if (ref >= 0)
+    return shape_ray_intersection(s, ref, ray_world, out);
+  hit_t hits[MAX_HITS];
+  int n = csg_all_ray_intersections(s, ~ref, ray_world, hits);
+  if (n == 0)
+    return 0;
+  *out = hits[0];
+  return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * World — include/shapes.hpp:520-604
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t rays;
+  uint64_t capped;
+} counters_t;
+
+/* World::ray_intersection — include/shapes.hpp:547-561.  Returns object index or -1. */
+static int world_ray_intersection(S *s, ray_t ray, hit_t *closest, counters_t *cnt) {
+  int best = -1;
+  if (cnt) cnt->rays++;
+  for (uint32_t i = 0; i < s->n_objects; ++i) {
+    hit_t h;
+    if (object_ray_intersection(s, s->objects[i], ray, &h) && h.t < (best >= 0 ? closest->t : INFINITY)) {
+      *closest = h;
+      best = (int)i;
+    }
+  }
+  return best;
+}
+
+/* World::on_off_ray_intersection — include/shapes.hpp:567-578 */
+static int world_on_off_ray_intersection(S *s, ray_t ray, counters_t *cnt) {
+  if (cnt) cnt->rays++;
+  for (uint32_t i = 0; i < s->n_objects; ++i) {
+    hit_t h;
+    if (object_ray_intersection(s, s->objects[i], ray, &h))
+      return 1;
+  }
+  return 0;
+}
+
+/* World::offset_if_visible — include/shapes.hpp:584-603 */
+static int world_offset_if_visible(S *s, v3 viewer, v3 surface, v3 normal, v3 *in_dir_out, counters_t *cnt) {
+  v3 in_dir = sub3(surface, viewer);
+  ray_t in_ray = {viewer, in_dir, 1e-5f, INFINITY, 0};
+  if (cnt) cnt->rays++;
+  if (dot3(in_dir, normal) > 0.f)
+    return 0;
+  for (uint32_t i = 0; i < s->n_objects; ++i) {
+    hit_t h;
+    if (object_ray_intersection(s, s->objects[i], in_ray, &h) && h.t < 1.f && !point_is_close(h.point, surface))
+      return 0;
+  }
+  *in_dir_out = in_dir;
+  return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Materials — include/materials.hpp
+ * ------------------------------------------------------------------------------------------ */
+
+/* UniformPigment / CheckeredPigment / ImagePigment::operator() — include/materials.hpp:64,85-94,120-137 */
+static col3 pigment_eval(S *s, uint32_t pg, float u, float v) {
+  col3 c;
+  const float *c1 = s->pigment_color1 + 3 * pg, *c2 = s->pigment_color2 + 3 * pg;
+  switch (s->pigment_kind[pg]) {
+  case RT_PIGMENT_CHECKERED: {
+    float subinterval = 1.f / (float)s->pigment_n_intervals[pg]; /* materials.hpp:81 */
+    int col = (int)(u / subinterval);
+    int row = (int)(v / subinterval);
+    const float *k = ((col + row) % 2 == 0) ? c1 : c2;
+    c.r = k[0], c.g = k[1], c.b = k[2];
+    return c;
+  }
+  case RT_PIGMENT_IMAGE: {
+    int w = s->pigment_tex_width[pg], h = s->pigment_tex_height[pg];
+    int col = (int)(u * (float)w);
+    int row = (int)(v * (float)h);
+    if (col >= w) col = w - 1;
+    if (row >= h) row = h - 1;
+    const float *px = s->texels + 3 * ((size_t)s->pigment_tex_offset[pg] + (size_t)row * (size_t)w + (size_t)col);
+    c.r = px[0], c.g = px[1], c.b = px[2];
+    return c;
+  }
+  default:
+    c.r = c1[0], c.g = c1[1], c.b = c1[2];
+    return c;
+  }
+}
+
+/* DiffusiveBRDF::scatter_ray / SpecularBRDF::scatter_ray — include/materials.hpp:199-211, 252-261 */
+static ray_t brdf_scatter_ray(int brdf_kind, pcg_t *pcg, v3 in_dir, v3 point, v3 normal, int depth) {
+  ray_t r;
+  r.o = point;
+  r.tmax = INFINITY;
+  r.depth = depth;
+  if (brdf_kind == RT_BRDF_SPECULAR) {
+    in_dir = normalized3(in_dir);
+    v3 n = normalized3(normal);
+    r.d = sub3(in_dir, scale3(scale3(n, 2.f), dot3(n, in_dir)));
+    r.tmin = 1.e-5f;
+    return r;
+  }
+  v3 e3 = normalized3(normal), e1, e2;
+  onb_from_e3(e3, &e1, &e2);
+  float theta, phi;
+  pcg_random_phong(pcg, 1, &theta, &phi);
+  v3 a = scale3(scale3(e1, sinf(theta)), cosf(phi));
+  v3 b = scale3(scale3(e2, sinf(theta)), sinf(phi));
+  v3 c = scale3(e3, cosf(theta));
+  r.d = add3(add3(a, b), c);
+  r.tmin = 1.e-3f;
+  return r;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Renderers — include/renderers.hpp
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  S *s;
+  const rt_render_cfg *cfg;
+  pcg_t *path_pcg;
+  counters_t cnt;
+} ctx_t;
+
+static col3 c_add(col3 a, col3 b) { col3 r = {a.r + b.r, a.g + b.g, a.b + b.b}; return r; }     /* colors.hpp:118 */
+static col3 c_mul(col3 a, col3 b) { col3 r = {a.r * b.r, a.g * b.g, a.b * b.b}; return r; }     /* colors.hpp:127 */
+static col3 c_scale(col3 a, float k) { col3 r = {a.r * k, a.g * k, a.b * k}; return r; }        /* colors.hpp:136 */
+static col3 c_from(const float *p) { col3 r = {p[0], p[1], p[2]}; return r; }
+static const col3 C_BLACK = {0.f, 0.f, 0.f}, C_WHITE = {1.f, 1.f, 1.f};
+
+/* OnOffTracer::operator() — include/renderers.hpp:62-69 */
+static col3 shade_onoff(ctx_t *c, ray_t ray) {
+  return world_on_off_ray_intersection(c->s, ray, &c->cnt) ? C_WHITE : C_BLACK;
+}
+
+/* FlatTracer::operator() — include/renderers.hpp:88-96 */
+static col3 shade_flat(ctx_t *c, ray_t ray) {
+  hit_t h;
+  if (world_ray_intersection(c->s, ray, &h, &c->cnt) < 0)
+    return c_from(c->cfg->background);
+  uint32_t m = c->s->shape_material[h.shape];
+  return c_add(pigment_eval(c->s, c->s->material_brdf_pigment[m], h.u, h.v),
+               pigment_eval(c->s, c->s->material_emission_pigment[m], h.u, h.v));
+}
+
+/* PointLightTracer::operator() — include/renderers.hpp:121-172, plus the bounce cap the reference
+ * lacks (cfg->max_mirror_bounces <= 0: uncapped, exactly the reference, may not terminate). */
+static col3 shade_pointlight(ctx_t *c, ray_t ray) {
+  S *s = c->s;
+  hit_t h;
+  uint32_t m;
+  col3 attenuation = C_WHITE;
+  int bounces = 0;
+  for (;;) {
+    if (world_ray_intersection(s, ray, &h, &c->cnt) < 0)
+      return c_from(c->cfg->background);
+    m = s->shape_material[h.shape];
+    if (s->material_brdf[m] != RT_BRDF_SPECULAR)
+      break;
+    if (c->cfg->max_mirror_bounces > 0 && bounces++ >= c->cfg->max_mirror_bounces) {
+      c->cnt.capped++;
+      return c_from(c->cfg->background);
+    }
+    attenuation = c_mul(attenuation, pigment_eval(s, s->material_brdf_pigment[m], h.u, h.v));
+    v3 new_dir = sub3(ray.d, scale3(lscale3(2.f, h.normal), dot3(h.normal, ray.d)));
+    ray_t next = {h.point, new_dir, 1e-5f, INFINITY, 0};
+    ray = next;
+  }
+  col3 radiance = c_add(c_from(c->cfg->ambient), pigment_eval(s, s->material_emission_pigment[m], h.u, h.v));
+  for (uint32_t l = 0; l < s->n_lights; ++l) {
+    v3 lp = {s->light_point[3 * l], s->light_point[3 * l + 1], s->light_point[3 * l + 2]};
+    v3 in_dir;
+    if (!world_offset_if_visible(s, lp, h.point, h.normal, &in_dir, &c->cnt))
+      continue;
+    float distance = sqrtf(sqnorm3(in_dir));
+    float radius = s->light_radius[l];
+    /* std::pow(float, int) computes in double — include/renderers.hpp:164 */
+    float distance_factor = (radius > 0.f) ? (float)pow((double)(radius / distance), 2.0) : 1.f;
+    float cos_theta = dot3(lscale3(-1.f / distance, in_dir), normalized3(h.normal));
+    /* DiffusiveBRDF::eval — include/materials.hpp:195-197 (a specular brdf never reaches here) */
+    col3 brdf = c_scale(pigment_eval(s, s->material_brdf_pigment[m], h.u, h.v), 1.f / PI_F);
+    radiance = c_add(radiance, c_mul(c_scale(c_scale(c_from(s->light_color + 3 * l), distance_factor), cos_theta), brdf));
+  }
+  return c_mul(radiance, attenuation);
+}
+
+/* PathTracer::operator() — include/renderers.hpp:208-262 */
+static col3 shade_path(ctx_t *c, ray_t ray) {
+  S *s = c->s;
+  const rt_render_cfg *cfg = c->cfg;
+  if (ray.depth > cfg->max_depth)
+    return C_BLACK;
+  hit_t h;
+  if (world_ray_intersection(s, ray, &h, &c->cnt) < 0)
+    return c_from(cfg->background);
+  uint32_t m = s->shape_material[h.shape];
+  col3 reflected = pigment_eval(s, s->material_brdf_pigment[m], h.u, h.v);
+  col3 emitted = pigment_eval(s, s->material_emission_pigment[m], h.u, h.v);
+  float hit_lum = fmaxf(fmaxf(reflected.r, reflected.g), reflected.b);
+  if (ray.depth > cfg->roulette) {
+    float q = fmaxf(1.f - hit_lum, 0.05f);
+    if (pcg_random_float(c->path_pcg) > q)
+      reflected = c_scale(reflected, 1.f / (1.f - q));
+    else
+      return emitted;
+  }
+  col3 cum = C_BLACK;
+  if (hit_lum > 0.f) {
+    for (int i = 0; i < cfg->n_rays; ++i) {
+      ray_t new_ray = brdf_scatter_ray(s->material_brdf[m], c->path_pcg, ray.d, h.point, h.normal, ray.depth + 1);
+      cum = c_add(cum, shade_path(c, new_ray));
+    }
+  }
+  cum = c_mul(c_scale(cum, 1.f / (float)cfg->n_rays), reflected);
+  return c_add(cum, emitted);
+}
+
+static col3 shade(ctx_t *c, ray_t ray) {
+  switch (c->cfg->mode) {
+  case RT_MODE_ONOFF: return shade_onoff(c, ray);
+  case RT_MODE_FLAT: return shade_flat(c, ray);
+  case RT_MODE_POINTLIGHT: return shade_pointlight(c, ray);
+  default: return shade_path(c, ray);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Camera + ImageTracer — include/cameras.hpp
+ * ------------------------------------------------------------------------------------------ */
+
+/* ImageTracer::fire_ray + Camera::u_to_y / v_to_z + {Orthogonal,Perspective}Camera::fire_ray —
+ * include/cameras.hpp:200-208, 112-121, 133-137, 155-159 */
+static ray_t camera_fire_ray(const rt_camera *cam, int width, int height, int col, int row, float u_pixel, float v_pixel) {
+  float asp = cam->has_asp_ratio ? cam->asp_ratio : (float)width / (float)height; /* cameras.hpp:184-186 */
+  float u = ((float)col + u_pixel) / (float)width;
+  float v = 1.f - (((float)row + v_pixel) / (float)height);
+  float y = (1.f - u * 2.f) * asp; /* (SCREEN_MAX - u*SCREEN_RANGE)*asp */
+  float z = -1.f + v * 2.f;        /* SCREEN_MIN + v*SCREEN_RANGE       */
+  ray_t r;
+  r.tmin = 1e-5f;
+  r.tmax = INFINITY;
+  r.depth = 0;
+  if (cam->kind == RT_CAMERA_PERSPECTIVE) {
+    r.o.x = -cam->distance, r.o.y = 0.f, r.o.z = 0.f;
+    r.d.x = cam->distance, r.d.y = y, r.d.z = z;
+  } else {
+    r.o.x = -1.f, r.o.y = y, r.o.z = z;
+    r.d.x = 1.f, r.d.y = 0.f, r.d.z = 0.f;
+  }
+  return ray_transform(r, cam->fwd);
+}
+
+static int check_cfg(const rt_render_cfg *cfg) {
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->spp_edge < 1 || cfg->mode > RT_MODE_PATH)
+    return 0;
+  if (cfg->band_rows <= 0 || cfg->band_stride < cfg->band_rows || cfg->band_offset < 0 || cfg->n_local_rows < 0)
+    return 0;
+  if (cfg->mode == RT_MODE_PATH && cfg->n_rays < 1)
+    return 0;
+  return 1;
+}
+
+static int local_to_image_row(const rt_render_cfg *cfg, int lr) {
+  return (lr / cfg->band_rows) * cfg->band_stride + cfg->band_offset + lr % cfg->band_rows;
+}
+
+/*
+ * ImageTracer::fire_all_rays — include/cameras.hpp:221-251.
+ *
+ * Whole image + RT_RNG_SERIAL_REFERENCE: literally the reference loop (columns outer, rows inner,
+ * one serial AA PCG(42,54) — the ctor quirk Q1 of SURVEY.md §8a — and one serial path PCG(42,seq)).
+ * Otherwise (row bands and/or per-sample streams): the AA draws are addressed by the index they
+ * have in the reference's serial order, 2*((col*H+row)*spp^2 + i*spp + j) + {0,1}, via jump-ahead.
+ */
+RTO_EXPORT int rto_render(const rt_scene_desc *s, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out,
+                          rt_stats *stats) {
+  if (!s || !cam || !cfg || !rgb_out || !check_cfg(cfg))
+    return RT_ERR_INVALID_ARGUMENT;
+  const int W = cfg->width, H = cfg->height, spp = cfg->spp_edge;
+  const int whole = (cfg->band_rows == H && cfg->band_offset == 0 && cfg->n_local_rows == H);
+  pcg_t aa_pcg, path_pcg;
+  pcg_init(&aa_pcg, 42ull, 54ull);
+  pcg_init(&path_pcg, 42ull, cfg->seq_number);
+  ctx_t ctx = {s, cfg, &path_pcg, {0, 0}};
+  uint64_t samples = 0;
+  const int serial = (cfg->rng_mode == RT_RNG_SERIAL_REFERENCE);
+  if (serial && !whole)
+    return RT_ERR_INVALID_ARGUMENT; /* a serial stream cannot be sharded */
+
+  for (int col = 0; col < W; ++col) {
+    for (int lr = 0; lr < cfg->n_local_rows; ++lr) {
+      const int row = local_to_image_row(cfg, lr);
+      if (row >= H)
+        return RT_ERR_INVALID_ARGUMENT;
+      col3 cum = C_BLACK;
+      if (spp > 1) {
+        for (int i = 0; i < spp; ++i) {
+          for (int j = 0; j < spp; ++j) {
+            const uint64_t k = ((uint64_t)col * (uint64_t)H + (uint64_t)row) * (uint64_t)(spp * spp) + (uint64_t)(i * spp + j);
+            if (!serial) {
+              pcg_init(&aa_pcg, 42ull, 54ull);
+              pcg_advance(&aa_pcg, 2 * k);
+            }
+            float u_pixel = ((float)i + pcg_random_float(&aa_pcg)) / (float)spp;
+            float v_pixel = ((float)j + pcg_random_float(&aa_pcg)) / (float)spp;
+            if (!serial) {
+              const uint64_t g = ((uint64_t)row * (uint64_t)W + (uint64_t)col) * (uint64_t)(spp * spp) + (uint64_t)(i * spp + j);
+              sample_stream(&path_pcg, cfg->seq_number, g);
+            }
+            cum = c_add(cum, shade(&ctx, camera_fire_ray(cam, W, H, col, row, u_pixel, v_pixel)));
+            ++samples;
+          }
+        }
+        cum = c_scale(cum, 1.f / (float)(spp * spp)); /* Color::operator/ — colors.hpp:145 */
+      } else {
+        if (!serial)
+          sample_stream(&path_pcg, cfg->seq_number, (uint64_t)row * (uint64_t)W + (uint64_t)col);
+        cum = shade(&ctx, camera_fire_ray(cam, W, H, col, row, 0.5f, 0.5f));
+        ++samples;
+      }
+      float *px = rgb_out + 3 * ((size_t)lr * (size_t)W + (size_t)col); /* HdrImage::set_pixel — colors.hpp:448-464 */
+      px[0] = cum.r, px[1] = cum.g, px[2] = cum.b;
+    }
+  }
+  if (stats) {
+    stats->rays = ctx.cnt.rays;
+    stats->samples = samples;
+    stats->capped_samples = ctx.cnt.capped;
+    stats->kernel_ms = 0.f;
+  }
+  return RT_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Fine-grained entry points for the known-answer tests
+ * ------------------------------------------------------------------------------------------ */
+static ray_t ray_from_abi(const rt_ray *r) {
+  ray_t q = {{r->origin[0], r->origin[1], r->origin[2]}, {r->direction[0], r->direction[1], r->direction[2]}, r->tmin, r->tmax, 0};
+  return q;
+}
+
+static void ray_to_abi(ray_t r, rt_ray *out) {
+  out->origin[0] = r.o.x, out->origin[1] = r.o.y, out->origin[2] = r.o.z;
+  out->direction[0] = r.d.x, out->direction[1] = r.d.y, out->direction[2] = r.d.z;
+  out->tmin = r.tmin, out->tmax = r.tmax;
+}
+
+static void hit_to_abi(int object, const hit_t *h, rt_hit *out) {
+  memset(out, 0, sizeof *out);
+  out->object = object;
+  out->shape = -1;
+  if (object < 0)
+    return;
+  out->shape = h->shape;
+  out->t = h->t;
+  out->point[0] = h->point.x, out->point[1] = h->point.y, out->point[2] = h->point.z;
+  out->normal[0] = h->normal.x, out->normal[1] = h->normal.y, out->normal[2] = h->normal.z;
+  out->uv[0] = h->u, out->uv[1] = h->v;
+}
+
+/* World::ray_intersection for a batch */
+RTO_EXPORT int rto_trace_rays(const rt_scene_desc *s, const rt_ray *rays, size_t n, rt_hit *hits) {
+  for (size_t i = 0; i < n; ++i) {
+    hit_t h;
+    int obj = world_ray_intersection(s, ray_from_abi(&rays[i]), &h, NULL);
+    hit_to_abi(obj, &h, &hits[i]);
+  }
+  return RT_OK;
+}
+
+/* World::offset_if_visible for a batch */
+RTO_EXPORT int rto_offset_if_visible(const rt_scene_desc *s, const float *viewer, const float *surface,
+                                     const float *normal, size_t n, uint8_t *visible) {
+  for (size_t i = 0; i < n; ++i) {
+    v3 a = {viewer[3 * i], viewer[3 * i + 1], viewer[3 * i + 2]};
+    v3 b = {surface[3 * i], surface[3 * i + 1], surface[3 * i + 2]};
+    v3 c = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+    v3 d;
+    visible[i] = (uint8_t)world_offset_if_visible(s, a, b, c, &d, NULL);
+  }
+  return RT_OK;
+}
+
+/* Object::all_ray_intersections of one object reference: hit records ordered by t */
+RTO_EXPORT int rto_object_all_hits(const rt_scene_desc *s, rt_ref object, const rt_ray *ray, rt_hit *hits, int cap) {
+  hit_t tmp[MAX_HITS];
+  int n = object_all_ray_intersections(s, object, ray_from_abi(ray), tmp);
+  for (int i = 0; i < n && i < cap; ++i)
+    hit_to_abi(0, &tmp[i], &hits[i]);
+  return n;
+}
+
+/* Object::ray_intersection of one object reference */
+RTO_EXPORT int rto_object_hit(const rt_scene_desc *s, rt_ref object, const rt_ray *ray, rt_hit *hit) {
+  hit_t h;
+  int ok = object_ray_intersection(s, object, ray_from_abi(ray), &h);
+  hit_to_abi(ok ? 0 : -1, &h, hit);
+  return ok;
+}
+
+RTO_EXPORT int rto_is_point_inside(const rt_scene_desc *s, rt_ref object, const float p[3]) {
+  v3 q = {p[0], p[1], p[2]};
+  return object_is_point_inside(s, object, q);
+}
+
+RTO_EXPORT void rto_pcg_init(uint64_t st[2], uint64_t init_state, uint64_t init_seq) {
+  pcg_t p;
+  pcg_init(&p, init_state, init_seq);
+  st[0] = p.state, st[1] = p.inc;
+}
+RTO_EXPORT uint32_t rto_pcg_random(uint64_t st[2]) {
+  pcg_t p = {st[0], st[1]};
+  uint32_t r = pcg_random(&p);
+  st[0] = p.state;
+  return r;
+}
+RTO_EXPORT float rto_pcg_random_float(uint64_t st[2]) {
+  pcg_t p = {st[0], st[1]};
+  float r = pcg_random_float(&p);
+  st[0] = p.state;
+  return r;
+}
+RTO_EXPORT void rto_pcg_advance(uint64_t st[2], uint64_t n) {
+  pcg_t p = {st[0], st[1]};
+  pcg_advance(&p, n);
+  st[0] = p.state;
+}
+RTO_EXPORT void rto_sample_stream(uint64_t st[2], uint64_t seq_number, uint64_t global_sample) {
+  pcg_t p;
+  sample_stream(&p, seq_number, global_sample);
+  st[0] = p.state, st[1] = p.inc;
+}
+
+/* The AA jitter pair of serial sample index k (include/cameras.hpp:232-233) via jump-ahead */
+RTO_EXPORT void rto_aa_jitter(const uint64_t *k, size_t n, float *u, float *v) {
+  for (size_t i = 0; i < n; ++i) {
+    pcg_t p;
+    pcg_init(&p, 42ull, 54ull);
+    pcg_advance(&p, 2 * k[i]);
+    u[i] = pcg_random_float(&p);
+    v[i] = pcg_random_float(&p);
+  }
+}
+
+/* BRDF::scatter_ray */
+RTO_EXPORT void rto_scatter_ray(int brdf_kind, uint64_t st[2], const float in_dir[3], const float point[3],
+                                const float normal[3], int depth, rt_ray *out) {
+  pcg_t p = {st[0], st[1]};
+  v3 a = {in_dir[0], in_dir[1], in_dir[2]}, b = {point[0], point[1], point[2]}, c = {normal[0], normal[1], normal[2]};
+  ray_to_abi(brdf_scatter_ray(brdf_kind, &p, a, b, c, depth), out);
+  st[0] = p.state;
+}
+
+RTO_EXPORT void rto_pigment(const rt_scene_desc *s, uint32_t pigment, float u, float v, float out[3]) {
+  col3 c = pigment_eval(s, pigment, u, v);
+  out[0] = c.r, out[1] = c.g, out[2] = c.b;
+}
+
+RTO_EXPORT void rto_onb(const float e3[3], float e1[3], float e2[3]) {
+  v3 a = {e3[0], e3[1], e3[2]}, b, c;
+  onb_from_e3(a, &b, &c);
+  e1[0] = b.x, e1[1] = b.y, e1[2] = b.z;
+  e2[0] = c.x, e2[1] = c.y, e2[2] = c.z;
+}
+
+/* ImageTracer::fire_ray */
+RTO_EXPORT void rto_camera_ray(const rt_camera *cam, int width, int height, int col, int row, float u_pixel,
+                               float v_pixel, rt_ray *out) {
+  ray_to_abi(camera_fire_ray(cam, width, height, col, row, u_pixel, v_pixel), out);
+}
+
+/* Renderer::operator()(ray) for one ray; st = path PCG state (in/out). */
+RTO_EXPORT int rto_shade(const rt_scene_desc *s, const rt_render_cfg *cfg, const rt_ray *ray, int depth, uint64_t st[2],
+                         float out[3], uint64_t *rays) {
+  pcg_t p = {st[0], st[1]};
+  ctx_t ctx = {s, cfg, &p, {0, 0}};
+  ray_t r = ray_from_abi(ray);
+  r.depth = depth;
+  col3 c = shade(&ctx, r);
+  out[0] = c.r, out[1] = c.g, out[2] = c.b;
+  st[0] = p.state;
+  if (rays) *rays = ctx.cnt.rays;
+  return RT_OK;
+}
+
+/* Transformation products for the geometry known answers (test/geometry_test.cpp:114-134) */
+RTO_EXPORT void rto_hom_apply(const float m[12], const float inv[12], int what, const float in[3], float out[3]) {
+  v3 a = {in[0], in[1], in[2]}, r;
+  if (what == 0) r = hom_apply_vec(m, a);
+  else if (what == 1) r = hom_apply_point(m, a);
+  else r = hom_apply_transposed(inv, a);
+  out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}

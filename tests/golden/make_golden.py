@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* by RUNNING THE UNMODIFIED REFERENCE (oracle/_ref/rt_ref, built by
+oracle/Makefile from /root/reference) on the reference's own sample scenes.
+
+Only runnable where /root/reference exists (the build container).  The outputs are data: flattened
+scenes, images, hit records.  Re-run with:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_lib import REF_BIN, read_pfm  # noqa: E402
+
+SAMPLES = "/root/reference/samples"
+SCENES = {"demo_onoff": "demo_onoff_tracing.txt", "demo_path": "demo_path_tracing.txt", "csg_example": "csg_example.txt"}
+TMP = tempfile.mkdtemp(prefix="rtgold")
+
+
+def ref(*args):
+    out = subprocess.run([REF_BIN, *map(str, args)], check=True, capture_output=True, text=True).stdout
+    return out
+
+
+def render(scene, mode, w, h, aa=1, **kw):
+    pfm = os.path.join(TMP, "o.pfm")
+    args = ["render", os.path.join(SAMPLES, SCENES[scene]), "-o", pfm, "--mode", mode, "--width", w, "--height", h, "--aa", aa]
+    for k, v in kw.items():
+        args += ["--" + k.replace("_", "-") if k != "n_rays" else "--n_rays", v]
+    info = json.loads(ref(*args))
+    return read_pfm(pfm), info
+
+
+def random_rays(rng, n, scene):
+    """Rays aimed roughly at the scene content, from points on a shell around it, plus grazing ones."""
+    o = rng.normal(size=(n, 3)).astype(np.float32)
+    o = (o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(0.2, 6.0, size=(n, 1))).astype(np.float32)
+    target = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    d *= rng.uniform(0.1, 3.0, size=(n, 1)).astype(np.float32)  # directions are NOT normalised in the reference
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3:6] = o, d
+    rays[:, 6] = np.where(rng.random(n) < 0.5, 1e-5, 1e-3)
+    rays[:, 7] = np.where(rng.random(n) < 0.8, np.inf, rng.uniform(0.5, 5.0, size=n))
+    return rays
+
+
+def main():
+    meta = {}
+    # 1. flattened scenes (World/Camera as parsed by the reference)
+    for name, f in SCENES.items():
+        ref("flatten", os.path.join(SAMPLES, f), os.path.join(HERE, f"{name}.scene.json"))
+    ref("flatten", os.path.join(SAMPLES, SCENES["demo_path"]), os.path.join(HERE, "demo_path_clock30.scene.json"),
+        "--define", "clock=30")
+
+    # 2. C1: onoff mask 1280x960 (bit-packed) + count + sha256 of the PFM
+    pfm = os.path.join(TMP, "onoff.pfm")
+    ref("render", os.path.join(SAMPLES, SCENES["demo_onoff"]), "-o", pfm, "--mode", "onoff", "--width", 1280, "--height", 960)
+    img = read_pfm(pfm)
+    mask = img[..., 0] > 0
+    assert set(np.unique(img)) <= {0.0, 1.0}
+    np.save(os.path.join(HERE, "onoff_demo_onoff_1280x960.maskbits.npy"), np.packbits(mask))
+    meta["onoff_demo_onoff_1280x960"] = {"hit_pixels": int(mask.sum()), "pfm_sha256": hashlib.sha256(open(pfm, "rb").read()).hexdigest()}
+
+    images = {}
+    # 3. deterministic modes, small sizes, AA=1 and AA=2 (AA=2 pins the exact-jitter claim)
+    for aa in (1, 2):
+        images[f"flat_demo_path_160x120_aa{aa}"], _ = render("demo_path", "flat", 160, 120, aa)
+        images[f"pointlight_demo_path_160x120_aa{aa}"], info = render("demo_path", "pointlight", 160, 120, aa, cap=64)
+        meta[f"pointlight_demo_path_160x120_aa{aa}"] = info
+        images[f"onoff_demo_onoff_160x120_aa{aa}"], _ = render("demo_onoff", "onoff", 160, 120, aa)
+        images[f"pointlight_demo_onoff_160x120_aa{aa}"], _ = render("demo_onoff", "pointlight", 160, 120, aa, cap=64)
+        images[f"flat_csg_example_240x135_aa{aa}"], _ = render("csg_example", "flat", 240, 135, aa)
+        images[f"onoff_csg_example_240x135_aa{aa}"], _ = render("csg_example", "onoff", 240, 135, aa)
+    images["flat_demo_path_clock30_160x120_aa1"] = read_pfm(_render_clock30(os.path.join(TMP, "c30.pfm")))
+    # stock (uncapped) pointlight where the reference terminates: must equal the capped render
+    stock, _ = render("demo_path", "pointlight", 160, 120, 1)
+    assert np.array_equal(stock, images["pointlight_demo_path_160x120_aa1"])
+
+    # 4. path mode, the reference's serial PCG: small exact pins + high-spp statistical references
+    for scene in ("demo_path", "csg_example"):
+        images[f"path_{scene}_64x48_aa1_serial"], _ = render(scene, "path", 64, 48, 1, n_rays=10, roulette=3, max_depth=5, seq=54)
+        images[f"path_{scene}_32x24_aa2_serial_seq7"], _ = render(scene, "path", 32, 24, 2, n_rays=3, roulette=2, max_depth=4, seq=7)
+        images[f"path_{scene}_96x72_aa6_serial"], info = render(scene, "path", 96, 72, 6, n_rays=10, roulette=3, max_depth=5, seq=54)
+        meta[f"path_{scene}_96x72_aa6_serial"] = info
+    np.savez_compressed(os.path.join(HERE, "images.npz"), **images)
+
+    # 5. World::ray_intersection / offset_if_visible / CSG t-lists on seeded random rays
+    rng = np.random.default_rng(20260128)
+    traces = {}
+    for name, f in SCENES.items():
+        rays = random_rays(rng, 4096, name)
+        rp, hp = os.path.join(TMP, "rays.bin"), os.path.join(TMP, "hits.bin")
+        rays.tofile(rp)
+        ref("trace", os.path.join(SAMPLES, f), rp, hp)
+        rec = np.fromfile(hp, dtype=np.dtype([("object", "<i4"), ("rec", "<f4", 9)]))
+        traces[f"{name}_rays"] = rays
+        traces[f"{name}_object"] = rec["object"]
+        traces[f"{name}_rec"] = rec["rec"]
+        # shadow tests: light positions vs hit points of those rays
+        hit = rec["object"] >= 0
+        surf = rec["rec"][hit][:, 1:4]
+        nrm = rec["rec"][hit][:, 4:7]
+        viewer = rng.uniform(-3, 3, size=surf.shape).astype(np.float32)
+        tri = np.concatenate([viewer, surf, nrm], axis=1).astype(np.float32)
+        ip, op = os.path.join(TMP, "vis_in.bin"), os.path.join(TMP, "vis_out.bin")
+        tri.tofile(ip)
+        ref("visible", os.path.join(SAMPLES, f), ip, op)
+        traces[f"{name}_vis_in"] = tri
+        traces[f"{name}_vis_out"] = np.fromfile(op, dtype=np.uint8)
+    # CSG all_ray_intersections t-lists
+    rays = traces["csg_example_rays"][:1024]
+    rp, tp = os.path.join(TMP, "rays2.bin"), os.path.join(TMP, "ts.txt")
+    rays.tofile(rp)
+    ref("csg_ts", os.path.join(SAMPLES, SCENES["csg_example"]), rp, tp)
+    ts_rows = []
+    for line in open(tp):
+        parts = line.split()
+        ts_rows.append([float(parts[0]), float(parts[1]), float(len(parts) - 2)] + [float(x) for x in parts[2:]] + [np.nan] * (8 - (len(parts) - 2)))
+    traces["csg_example_tlists"] = np.array(ts_rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "traces.npz"), **traces)
+
+    with open(os.path.join(HERE, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta, indent=1))
+
+
+def _render_clock30(pfm):
+    ref("render", os.path.join(SAMPLES, SCENES["demo_path"]), "-o", pfm, "--mode", "flat", "--width", 160, "--height", 120,
+        "--define", "clock=30")
+    return pfm
+
+
+if __name__ == "__main__":
+    main()
