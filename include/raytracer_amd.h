@@ -31,6 +31,12 @@
 extern "C" {
 #endif
 
+#if defined(__GNUC__) || defined(__clang__)
+#define RT_API __attribute__((visibility("default")))
+#else
+#define RT_API
+#endif
+
 typedef enum rt_status {
   RT_OK = 0,
   RT_ERR_INVALID_ARGUMENT = 1, /* bad sizes / indices / enum values / limits exceeded           */
@@ -144,7 +150,8 @@ typedef struct rt_render_cfg {
   /*
    * The reference's PointLightTracer mirror loop has no bounce cap and can spin forever
    * (include/renderers.hpp:129-152).  A lane must never spin: after this many specular bounces
-   * the sample returns background*attenuation-so-far and is counted in rt_stats.capped_samples.
+   * the sample returns the background colour (what a miss returns) and is counted in
+   * rt_stats.capped_samples.
    */
   int32_t max_mirror_bounces;
   /*
@@ -192,17 +199,17 @@ typedef struct rt_scene rt_scene; /* opaque: device copy of a flattened World */
 /* Library / device ------------------------------------------------------------------------------ */
 
 /* Message of the last failing call on this thread ("" if none). Never NULL. */
-const char *rt_last_error(void);
+RT_API const char *rt_last_error(void);
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
-int rt_device_count(void);
+RT_API int rt_device_count(void);
 
 /* Scene -------------------------------------------------------------------------------------------
  * Replaces: the World the reference hands to build_renderer (src/raytracer.cpp:147) — flattened
  * once, reused for any number of renders (animation frames change only the camera).
  * Validates every index / enum / CSG limit; copies the arrays to `device`. */
-rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
-void rt_scene_destroy(rt_scene *scene);
+RT_API rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+RT_API void rt_scene_destroy(rt_scene *scene);
 
 /* Render ------------------------------------------------------------------------------------------
  * Replaces: ImageTracer::fire_all_rays (include/cameras.hpp:221-251) driving
@@ -214,28 +221,28 @@ void rt_scene_destroy(rt_scene *scene);
  * stream:         hipStream_t as void* (NULL = default stream).  The call enqueues and returns;
  *                 it synchronises only if `stats` is non-NULL (to read the counters back).
  */
-rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
+RT_API rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
                     float *rgb_out_device, void *stream, rt_stats *stats);
 
 /* Same, into host memory (allocates a device framebuffer, renders, copies back, synchronises).
  * This is what the C++ adapter for the reference's ImageTracer calls. */
-rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
+RT_API rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
                          float *rgb_out_host, rt_stats *stats);
 
 /* Batch closest-hit --------------------------------------------------------------------------------
  * Replaces: World::ray_intersection (include/shapes.hpp:547-561) for n rays at once; one ray per
  * lane.  rays / hits are HOST pointers (debug / parity entry point, not a hot path). */
-rt_status rt_trace_rays(rt_scene *scene, const rt_ray *rays, size_t n, rt_hit *hits);
+RT_API rt_status rt_trace_rays(rt_scene *scene, const rt_ray *rays, size_t n, rt_hit *hits);
 
 /* Batch shadow test: World::offset_if_visible (include/shapes.hpp:584-603).
  * viewer/surface/normal: [n][3] host floats; visible[n] receives 1/0. */
-rt_status rt_offset_if_visible(rt_scene *scene, const float *viewer, const float *surface,
+RT_API rt_status rt_offset_if_visible(rt_scene *scene, const float *viewer, const float *surface,
                                const float *normal, size_t n, uint8_t *visible);
 
 /* Antialiasing jitter of sample k: the 2k-th and (2k+1)-th PCG(42,54).random_float()
  * (include/cameras.hpp:232-233, include/random.hpp:52-70), by LCG jump-ahead on the device.
  * Host pointers; parity entry point for the exact-jitter claim. */
-rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float *u_out, float *v_out);
+RT_API rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float *u_out, float *v_out);
 
 #ifdef __cplusplus
 }

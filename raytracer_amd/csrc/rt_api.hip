@@ -1,0 +1,545 @@
+// rt_api.hip — the C-ABI of include/raytracer_amd.h: scene upload, launches, parity entry points.
+// Host code only orchestrates; all arithmetic of the tracing loop is in rt_device.h / rt_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+rt_status fail(rt_status st, const std::string &msg) {
+  g_last_error = msg;
+  return st;
+}
+
+#define RT_HIP(call)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                           \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                                      \
+  } while (0)
+
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+} // namespace
+
+struct rt_scene {
+  int device = 0;
+  int n_cus = 0;
+  std::vector<void *> owned;     // scene tables, freed by rt_scene_destroy
+  rtd::Scene dev{};              // device pointers
+  unsigned long long *counters = nullptr; // 4 x u64
+  DeviceBuffer samples, stack;   // grow-only scratch reused across renders
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+template <typename T> rt_status upload(rt_scene *sc, const T *host, size_t n, const T **out) {
+  *out = nullptr;
+  void *d = nullptr;
+  RT_HIP(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
+  sc->owned.push_back(d);
+  if (n)
+    RT_HIP(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T *>(d);
+  return RT_OK;
+}
+template <typename T> rt_status upload(rt_scene *sc, const std::vector<T> &v, const T **out) {
+  return upload(sc, v.data(), v.size(), out);
+}
+
+rt_status ensure(DeviceBuffer &b, size_t bytes) {
+  if (b.bytes >= bytes)
+    return RT_OK;
+  if (b.ptr)
+    RT_HIP(hipFree(b.ptr));
+  b.ptr = nullptr;
+  b.bytes = 0;
+  RT_HIP(hipMalloc(&b.ptr, bytes));
+  b.bytes = bytes;
+  return RT_OK;
+}
+
+// ---- validation + CSG preprocessing ---------------------------------------------------------------
+
+struct CsgBuild {
+  const rt_scene_desc *d;
+  std::vector<rtd::CsgTop> tops;
+  std::vector<rtd::CsgLeaf> leaves;
+  std::vector<rtd::CsgStep> path;
+  std::vector<int32_t> prog_range; // [node][side][2]
+  std::vector<rtd::CsgProgEntry> prog;
+  std::vector<int32_t> prog_path;
+  std::string err;
+
+  bool ref_ok(rt_ref r, int32_t below_node) const {
+    if (r >= 0)
+      return static_cast<uint32_t>(r) < d->n_shapes;
+    const int32_t node = ~r;
+    return node >= 0 && node < below_node; // children precede their parent: no cycles
+  }
+
+  // leaves of the subtree `ref`, left to right, each with the chain root..parent
+  bool collect(rt_ref ref, std::vector<rtd::CsgStep> &chain, int top_index) {
+    if (ref >= 0) {
+      rtd::CsgLeaf leaf{};
+      leaf.shape = ref;
+      leaf.path_begin = static_cast<int32_t>(path.size());
+      leaf.path_len = static_cast<int32_t>(chain.size());
+      path.insert(path.end(), chain.begin(), chain.end());
+      leaves.push_back(leaf);
+      if (static_cast<int32_t>(leaves.size()) - tops[top_index].leaf_begin > RT_MAX_CSG_LEAVES) {
+        err = "CSG object has more than RT_MAX_CSG_LEAVES leaves";
+        return false;
+      }
+      return true;
+    }
+    const int32_t node = ~ref;
+    if (static_cast<int>(chain.size()) >= RT_MAX_CSG_DEPTH) {
+      err = "CSG nesting deeper than RT_MAX_CSG_DEPTH";
+      return false;
+    }
+    chain.push_back({node, 0});
+    if (!collect(d->csg_left[node], chain, top_index))
+      return false;
+    chain.back().side = 1;
+    if (!collect(d->csg_right[node], chain, top_index))
+      return false;
+    chain.pop_back();
+    return true;
+  }
+
+  // RPN "inside?" program of the subtree `ref`; `chain` = CSG nodes from the subtree root down
+  void program(rt_ref ref, std::vector<int32_t> &chain) {
+    if (ref >= 0) {
+      rtd::CsgProgEntry e{};
+      e.is_op = 0;
+      e.arg = ref;
+      e.path_begin = static_cast<int32_t>(prog_path.size());
+      e.path_len = static_cast<int32_t>(chain.size());
+      prog_path.insert(prog_path.end(), chain.begin(), chain.end());
+      prog.push_back(e);
+      return;
+    }
+    const int32_t node = ~ref;
+    chain.push_back(node);
+    program(d->csg_left[node], chain);
+    program(d->csg_right[node], chain);
+    chain.pop_back();
+    rtd::CsgProgEntry e{};
+    e.is_op = 1;
+    e.arg = d->csg_op[node];
+    prog.push_back(e);
+  }
+};
+
+rt_status validate_desc(const rt_scene_desc *d) {
+  auto need = [](const void *p, uint32_t n) { return n == 0 || p != nullptr; };
+  if (!need(d->shape_kind, d->n_shapes) || !need(d->shape_material, d->n_shapes) || !need(d->shape_fwd, d->n_shapes) ||
+      !need(d->shape_inv, d->n_shapes) || !need(d->csg_op, d->n_csg_nodes) || !need(d->csg_left, d->n_csg_nodes) ||
+      !need(d->csg_right, d->n_csg_nodes) || !need(d->csg_fwd, d->n_csg_nodes) || !need(d->csg_inv, d->n_csg_nodes) ||
+      !need(d->objects, d->n_objects) || !need(d->material_brdf, d->n_materials) ||
+      !need(d->material_brdf_pigment, d->n_materials) || !need(d->material_emission_pigment, d->n_materials) ||
+      !need(d->pigment_kind, d->n_pigments) || !need(d->pigment_color1, d->n_pigments) ||
+      !need(d->pigment_color2, d->n_pigments) || !need(d->pigment_n_intervals, d->n_pigments) ||
+      !need(d->pigment_tex_offset, d->n_pigments) || !need(d->pigment_tex_width, d->n_pigments) ||
+      !need(d->pigment_tex_height, d->n_pigments) || !need(d->texels, d->n_texels) ||
+      !need(d->light_point, d->n_lights) || !need(d->light_color, d->n_lights) || !need(d->light_radius, d->n_lights))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_desc: NULL array with a non-zero count");
+  for (uint32_t i = 0; i < d->n_shapes; ++i) {
+    if (d->shape_kind[i] > RT_SHAPE_PLANE)
+      return fail(RT_ERR_INVALID_ARGUMENT, "shape_kind out of range");
+    if (d->shape_material[i] >= d->n_materials)
+      return fail(RT_ERR_INVALID_ARGUMENT, "shape_material out of range");
+  }
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    if (d->material_brdf[i] > RT_BRDF_SPECULAR)
+      return fail(RT_ERR_INVALID_ARGUMENT, "material_brdf out of range");
+    if (d->material_brdf_pigment[i] >= d->n_pigments || d->material_emission_pigment[i] >= d->n_pigments)
+      return fail(RT_ERR_INVALID_ARGUMENT, "material pigment index out of range");
+  }
+  for (uint32_t i = 0; i < d->n_pigments; ++i) {
+    const uint8_t k = d->pigment_kind[i];
+    if (k > RT_PIGMENT_IMAGE)
+      return fail(RT_ERR_INVALID_ARGUMENT, "pigment_kind out of range");
+    if (k == RT_PIGMENT_CHECKERED && d->pigment_n_intervals[i] <= 0)
+      return fail(RT_ERR_INVALID_ARGUMENT, "checkered pigment needs n_intervals > 0");
+    if (k == RT_PIGMENT_IMAGE) {
+      const int64_t w = d->pigment_tex_width[i], h = d->pigment_tex_height[i];
+      if (w <= 0 || h <= 0 || static_cast<uint64_t>(d->pigment_tex_offset[i]) + static_cast<uint64_t>(w * h) > d->n_texels)
+        return fail(RT_ERR_INVALID_ARGUMENT, "image pigment texels out of range");
+    }
+  }
+  for (uint32_t i = 0; i < d->n_csg_nodes; ++i)
+    if (d->csg_op[i] > RT_CSG_FUSION)
+      return fail(RT_ERR_INVALID_ARGUMENT, "csg_op out of range");
+  return RT_OK;
+}
+
+rt_status check_cfg(const rt_render_cfg *cfg) {
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->spp_edge < 1 || cfg->spp_edge > 1024)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: width/height must be positive, 1 <= spp_edge <= 1024");
+  if (cfg->mode > RT_MODE_PATH)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: unknown mode");
+  if (cfg->band_rows <= 0 || cfg->band_stride < cfg->band_rows || cfg->band_offset < 0 || cfg->n_local_rows <= 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: bad row banding");
+  const int last = cfg->n_local_rows - 1;
+  const int64_t last_row = static_cast<int64_t>(last / cfg->band_rows) * cfg->band_stride + cfg->band_offset + last % cfg->band_rows;
+  if (last_row >= cfg->height)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: row banding reaches past the image height");
+  if (cfg->mode == RT_MODE_PATH) {
+    if (cfg->n_rays < 1 || cfg->n_rays > 65535 || cfg->max_depth < 0 || cfg->max_depth > 32766 || cfg->roulette < 0)
+      return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: path mode needs 1 <= n_rays <= 65535, 0 <= max_depth <= 32766, roulette >= 0");
+    if (cfg->n_rays > 1 && cfg->max_depth > 64)
+      return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: max_depth > 64 is supported only with n_rays == 1");
+    if (cfg->rng_mode != RT_RNG_PER_SAMPLE_STREAMS)
+      return fail(RT_ERR_INVALID_ARGUMENT,
+                  "rt_render_cfg: the device renders path mode with per-sample streams only (RT_RNG_PER_SAMPLE_STREAMS)");
+  }
+  if (cfg->mode == RT_MODE_POINTLIGHT && cfg->max_mirror_bounces <= 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: pointlight needs max_mirror_bounces > 0 (a lane must never spin)");
+  return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
+  if (!d || !out)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: NULL argument");
+  *out = nullptr;
+  if (rt_status st = validate_desc(d))
+    return st;
+
+  // -- split World::objects into the scan lists, preprocess CSG trees ------------------------------
+  std::vector<rtd::ScanRec> spheres, planes;
+  CsgBuild cb;
+  cb.d = d;
+  cb.prog_range.assign(static_cast<size_t>(d->n_csg_nodes) * 4, 0);
+  for (uint32_t node = 0; node < d->n_csg_nodes; ++node)
+    if (!cb.ref_ok(d->csg_left[node], static_cast<int32_t>(node)) || !cb.ref_ok(d->csg_right[node], static_cast<int32_t>(node)))
+      return fail(RT_ERR_INVALID_ARGUMENT, "csg child reference out of range (children must precede their parent)");
+  for (uint32_t node = 0; node < d->n_csg_nodes; ++node) {
+    for (int side = 0; side < 2; ++side) {
+      std::vector<int32_t> chain;
+      cb.prog_range[4 * node + 2 * side + 0] = static_cast<int32_t>(cb.prog.size());
+      cb.program(side == 0 ? d->csg_left[node] : d->csg_right[node], chain);
+      cb.prog_range[4 * node + 2 * side + 1] = static_cast<int32_t>(cb.prog.size());
+    }
+  }
+  for (uint32_t i = 0; i < d->n_objects; ++i) {
+    const rt_ref ref = d->objects[i];
+    if (!cb.ref_ok(ref, static_cast<int32_t>(d->n_csg_nodes)))
+      return fail(RT_ERR_INVALID_ARGUMENT, "objects[] reference out of range");
+    if (ref >= 0) {
+      rtd::ScanRec r{};
+      std::memcpy(r.inv, d->shape_inv + 12 * static_cast<size_t>(ref), sizeof r.inv);
+      r.object = static_cast<int32_t>(i);
+      r.shape = ref;
+      (d->shape_kind[ref] == RT_SHAPE_SPHERE ? spheres : planes).push_back(r);
+    } else {
+      rtd::CsgTop top{};
+      top.object = static_cast<int32_t>(i);
+      top.leaf_begin = static_cast<int32_t>(cb.leaves.size());
+      cb.tops.push_back(top);
+      std::vector<rtd::CsgStep> chain;
+      if (!cb.collect(ref, chain, static_cast<int>(cb.tops.size()) - 1))
+        return fail(RT_ERR_INVALID_ARGUMENT, cb.err);
+      cb.tops.back().leaf_end = static_cast<int32_t>(cb.leaves.size());
+    }
+  }
+  std::vector<uint8_t> needs_uv(d->n_materials);
+  for (uint32_t m = 0; m < d->n_materials; ++m)
+    needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
+                  d->pigment_kind[d->material_emission_pigment[m]] != RT_PIGMENT_UNIFORM;
+
+  // -- device ------------------------------------------------------------------------------------
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+    return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device visible");
+  if (device < 0 || device >= n_dev)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device index out of range");
+  RT_HIP(hipSetDevice(device));
+  rt_scene *sc = new (std::nothrow) rt_scene();
+  if (!sc)
+    return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
+  sc->device = device;
+  hipDeviceProp_t prop;
+  rt_status st = RT_OK;
+  auto bail = [&](rt_status s) {
+    rt_scene_destroy(sc);
+    return s;
+  };
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
+  sc->n_cus = prop.multiProcessorCount;
+
+  rtd::Scene &S = sc->dev;
+#define UP(expr)                                                                                           \
+  if ((st = (expr)) != RT_OK)                                                                              \
+  return bail(st)
+  UP(upload(sc, spheres, &S.spheres));
+  UP(upload(sc, planes, &S.planes));
+  UP(upload(sc, cb.tops, &S.csg_tops));
+  S.n_spheres = static_cast<int32_t>(spheres.size());
+  S.n_planes = static_cast<int32_t>(planes.size());
+  S.n_csg_tops = static_cast<int32_t>(cb.tops.size());
+  S.n_objects = static_cast<int32_t>(d->n_objects);
+  UP(upload(sc, d->shape_fwd, 12 * static_cast<size_t>(d->n_shapes), &S.shape_fwd));
+  UP(upload(sc, d->shape_inv, 12 * static_cast<size_t>(d->n_shapes), &S.shape_inv));
+  UP(upload(sc, d->shape_kind, d->n_shapes, &S.shape_kind));
+  UP(upload(sc, d->shape_material, d->n_shapes, &S.shape_material));
+  UP(upload(sc, cb.leaves, &S.csg_leaf));
+  UP(upload(sc, cb.path, &S.csg_path));
+  UP(upload(sc, d->csg_fwd, 12 * static_cast<size_t>(d->n_csg_nodes), &S.csg_fwd));
+  UP(upload(sc, d->csg_inv, 12 * static_cast<size_t>(d->n_csg_nodes), &S.csg_inv));
+  UP(upload(sc, d->csg_op, d->n_csg_nodes, &S.csg_op));
+  UP(upload(sc, cb.prog_range, &S.csg_prog_range));
+  UP(upload(sc, cb.prog, &S.csg_prog));
+  UP(upload(sc, cb.prog_path, &S.csg_prog_path));
+  UP(upload(sc, d->material_brdf, d->n_materials, &S.material_brdf));
+  UP(upload(sc, d->material_brdf_pigment, d->n_materials, &S.material_brdf_pigment));
+  UP(upload(sc, d->material_emission_pigment, d->n_materials, &S.material_emission_pigment));
+  UP(upload(sc, needs_uv, &S.material_needs_uv));
+  UP(upload(sc, d->pigment_kind, d->n_pigments, &S.pigment_kind));
+  UP(upload(sc, d->pigment_color1, 3 * static_cast<size_t>(d->n_pigments), &S.pigment_color1));
+  UP(upload(sc, d->pigment_color2, 3 * static_cast<size_t>(d->n_pigments), &S.pigment_color2));
+  UP(upload(sc, d->pigment_n_intervals, d->n_pigments, &S.pigment_n_intervals));
+  UP(upload(sc, d->pigment_tex_offset, d->n_pigments, &S.pigment_tex_offset));
+  UP(upload(sc, d->pigment_tex_width, d->n_pigments, &S.pigment_tex_width));
+  UP(upload(sc, d->pigment_tex_height, d->n_pigments, &S.pigment_tex_height));
+  UP(upload(sc, d->texels, 3 * static_cast<size_t>(d->n_texels), &S.texels));
+  UP(upload(sc, d->light_point, 3 * static_cast<size_t>(d->n_lights), &S.light_point));
+  UP(upload(sc, d->light_color, 3 * static_cast<size_t>(d->n_lights), &S.light_color));
+  UP(upload(sc, d->light_radius, d->n_lights, &S.light_radius));
+  S.n_lights = static_cast<int32_t>(d->n_lights);
+#undef UP
+  void *cnt = nullptr;
+  if (hipMalloc(&cnt, 4 * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed"));
+  sc->counters = static_cast<unsigned long long *>(cnt);
+  if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
+    return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+  *out = sc;
+  return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *sc) {
+  if (!sc)
+    return;
+  (void)hipSetDevice(sc->device);
+  for (void *p : sc->owned)
+    (void)hipFree(p);
+  if (sc->counters) (void)hipFree(sc->counters);
+  if (sc->samples.ptr) (void)hipFree(sc->samples.ptr);
+  if (sc->stack.ptr) (void)hipFree(sc->stack.ptr);
+  if (sc->ev0) (void)hipEventDestroy(sc->ev0);
+  if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+  delete sc;
+}
+
+rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device, void *stream_,
+                    rt_stats *stats) {
+  if (!sc || !cam || !cfg || !rgb_out_device)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
+  if (rt_status st = check_cfg(cfg))
+    return st;
+  if (cam->kind > RT_CAMERA_PERSPECTIVE)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_camera: unknown kind");
+  RT_HIP(hipSetDevice(sc->device));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+  rtd::RenderParams p{};
+  std::memcpy(p.cam.fwd, cam->fwd, sizeof p.cam.fwd);
+  // ImageTracer ctor: asp_ratio defaults to float(width)/float(height) — cameras.hpp:184-186
+  p.cam.asp = cam->has_asp_ratio ? cam->asp_ratio : static_cast<float>(cfg->width) / static_cast<float>(cfg->height);
+  p.cam.distance = cam->distance;
+  p.cam.kind = static_cast<int32_t>(cam->kind);
+  p.width = cfg->width, p.height = cfg->height, p.spp_edge = cfg->spp_edge, p.mode = static_cast<int32_t>(cfg->mode);
+  p.n_rays = cfg->n_rays, p.roulette = cfg->roulette, p.max_depth = cfg->max_depth;
+  p.max_mirror_bounces = cfg->max_mirror_bounces;
+  p.seq_number = cfg->seq_number;
+  std::memcpy(p.background, cfg->background, sizeof p.background);
+  std::memcpy(p.ambient, cfg->ambient, sizeof p.ambient);
+  p.band_rows = cfg->band_rows, p.band_stride = cfg->band_stride, p.band_offset = cfg->band_offset;
+  p.n_local_rows = cfg->n_local_rows;
+  const uint64_t n_pixels = static_cast<uint64_t>(cfg->n_local_rows) * static_cast<uint64_t>(cfg->width);
+  const int spp2 = cfg->spp_edge * cfg->spp_edge;
+  p.n_samples = n_pixels * static_cast<uint64_t>(spp2);
+  p.counters = sc->counters;
+
+  if (spp2 > 1) {
+    if (rt_status st = ensure(sc->samples, p.n_samples * 3 * sizeof(float)))
+      return st;
+    p.samples_out = static_cast<float *>(sc->samples.ptr);
+  } else {
+    p.samples_out = rgb_out_device;
+  }
+
+  constexpr int BLOCK = 256;
+  unsigned grid;
+  if (cfg->mode == RT_MODE_PATH) {
+    int per_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path, BLOCK, 0));
+    per_cu = std::max(per_cu, 1);
+    const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
+    grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
+    p.n_lanes = grid * BLOCK;
+    p.stack_levels = cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1);
+    if (rt_status st = ensure(sc->stack, static_cast<size_t>(p.stack_levels) * rtd::STACK_WORDS * p.n_lanes * sizeof(float)))
+      return st;
+    p.stack = static_cast<float *>(sc->stack.ptr);
+  } else {
+    const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
+    grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 32));
+  }
+
+  RT_HIP(hipMemsetAsync(sc->counters, 0, 4 * sizeof(unsigned long long), stream));
+  if (stats)
+    RT_HIP(hipEventRecord(sc->ev0, stream));
+  switch (cfg->mode) {
+  case RT_MODE_ONOFF: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_ONOFF>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
+  case RT_MODE_FLAT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_FLAT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
+  case RT_MODE_POINTLIGHT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_POINTLIGHT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
+  default: hipLaunchKernelGGL(rtd::k_render_path, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
+  }
+  RT_HIP(hipGetLastError());
+  if (spp2 > 1) {
+    const unsigned rgrid = static_cast<unsigned>((n_pixels + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(rtd::k_resolve, dim3(rgrid), dim3(BLOCK), 0, stream, p.samples_out, rgb_out_device, n_pixels, spp2);
+    RT_HIP(hipGetLastError());
+  }
+  if (stats) {
+    RT_HIP(hipEventRecord(sc->ev1, stream));
+    RT_HIP(hipEventSynchronize(sc->ev1));
+    unsigned long long c[4];
+    RT_HIP(hipMemcpy(c, sc->counters, sizeof c, hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+    stats->rays = c[1];
+    stats->samples = p.n_samples;
+    stats->capped_samples = c[2];
+    stats->kernel_ms = ms;
+  }
+  return RT_OK;
+}
+
+rt_status rt_render_host(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, rt_stats *stats) {
+  if (!sc || !cfg || !rgb_out_host)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_host: NULL argument");
+  if (rt_status st = check_cfg(cfg))
+    return st;
+  RT_HIP(hipSetDevice(sc->device));
+  const size_t bytes = static_cast<size_t>(cfg->n_local_rows) * cfg->width * 3 * sizeof(float);
+  float *fb = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&fb), bytes));
+  rt_status st = rt_render(sc, cam, cfg, fb, nullptr, stats);
+  if (st == RT_OK) {
+    hipError_t e = hipMemcpy(rgb_out_host, fb, bytes, hipMemcpyDeviceToHost); // synchronises the default stream
+    if (e != hipSuccess)
+      st = fail(RT_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(fb);
+  return st;
+}
+
+rt_status rt_trace_rays(rt_scene *sc, const rt_ray *rays, size_t n, rt_hit *hits) {
+  if (!sc || (n && (!rays || !hits)))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_rays: NULL argument");
+  if (n == 0)
+    return RT_OK;
+  RT_HIP(hipSetDevice(sc->device));
+  rt_ray *d_rays = nullptr;
+  rt_hit *d_hits = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_rays), n * sizeof(rt_ray)));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_hits), n * sizeof(rt_hit));
+  if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rtd::k_trace_rays, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, sc->dev, d_rays, n, d_hits);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hits);
+  if (e != hipSuccess)
+    return fail(RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+rt_status rt_offset_if_visible(rt_scene *sc, const float *viewer, const float *surface, const float *normal, size_t n,
+                               uint8_t *visible) {
+  if (!sc || (n && (!viewer || !surface || !normal || !visible)))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_offset_if_visible: NULL argument");
+  if (n == 0)
+    return RT_OK;
+  RT_HIP(hipSetDevice(sc->device));
+  float *d_in = nullptr;
+  uint8_t *d_out = nullptr;
+  const size_t fb = 3 * n * sizeof(float);
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_in), 3 * fb));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), n);
+  if (e == hipSuccess) e = hipMemcpy(d_in, viewer, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_in + 3 * n, surface, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_in + 6 * n, normal, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rtd::k_offset_if_visible, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, sc->dev, d_in,
+                       d_in + 3 * n, d_in + 6 * n, n, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(visible, d_out, n, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess)
+    return fail(RT_ERR_HIP, std::string("rt_offset_if_visible: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float *u_out, float *v_out) {
+  if (n && (!sample_index || !u_out || !v_out))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_aa_jitter: NULL argument");
+  if (n == 0)
+    return RT_OK;
+  RT_HIP(hipSetDevice(device));
+  uint64_t *d_k = nullptr;
+  float *d_uv = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_k), n * sizeof(uint64_t)));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_uv), 2 * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(d_k, sample_index, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rtd::k_aa_jitter, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, d_k, n, d_uv, d_uv + n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(u_out, d_uv, n * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(v_out, d_uv + n, n * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_k);
+  (void)hipFree(d_uv);
+  if (e != hipSuccess)
+    return fail(RT_ERR_HIP, std::string("rt_aa_jitter: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+} // extern "C"

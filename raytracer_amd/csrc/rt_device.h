@@ -1,0 +1,523 @@
+// rt_device.h — device functions of the tracing loop (gfx950).  Compiled with -ffp-contract=off:
+// every predicate that decides hit / no-hit uses the reference's fp32 operation order without
+// fusing, so that the deterministic modes reproduce the reference's decisions.
+// Citations are to the reference sources (paths relative to the reference root).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/raytracer_amd.h"
+#include "rt_types.h"
+
+namespace rtd {
+
+#define RT_DEV __device__ __forceinline__
+
+constexpr float PI_F = 3.14159265358979323846f; // std::numbers::pi_v<float>
+constexpr float INF_F = __builtin_inff();
+
+struct V3 { float x, y, z; };
+struct Ray { V3 o, d; float tmin, tmax; }; // include/cameras.hpp:34-41
+
+RT_DEV V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // geometry.hpp:263-265
+RT_DEV float sqnorm3(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     // geometry.hpp:104
+RT_DEV V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 scale3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }   // Vec * scalar
+RT_DEV V3 lscale3(float s, V3 a) { return mk3(s * a.x, s * a.y, s * a.z); }  // scalar * Vec
+RT_DEV V3 mul3(V3 a, V3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }  // Color * Color
+
+// Vec::normalized — geometry.hpp:111-114
+RT_DEV V3 normalized3(V3 a) {
+  float n = sqrtf(sqnorm3(a));
+  return mk3(a.x / n, a.y / n, a.z / n);
+}
+
+// HomMatrix::apply(Vec) / apply(Point) / apply_transposed(Normal) — geometry.hpp:379-400
+template <typename P> RT_DEV V3 hom_vec(P m, V3 v) {
+  return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+             m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+template <typename P> RT_DEV V3 hom_point(P m, V3 p) {
+  return mk3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[9], m[3] * p.x + m[4] * p.y + m[5] * p.z + m[10],
+             m[6] * p.x + m[7] * p.y + m[8] * p.z + m[11]);
+}
+template <typename P> RT_DEV V3 hom_transposed(P m, V3 n) {
+  return mk3(m[0] * n.x + m[3] * n.y + m[6] * n.z, m[1] * n.x + m[4] * n.y + m[7] * n.z,
+             m[2] * n.x + m[5] * n.y + m[8] * n.z);
+}
+// Ray::transform — cameras.hpp:66
+template <typename P> RT_DEV Ray ray_transform(Ray r, P m) {
+  Ray q = r;
+  q.o = hom_point(m, r.o);
+  q.d = hom_vec(m, r.d);
+  return q;
+}
+
+// are_close / Point::is_close — colors.hpp:81, geometry.hpp:153-156
+RT_DEV bool are_close(float x, float y) { return fabsf(x - y) < 1e-5f; }
+RT_DEV bool point_is_close(V3 a, V3 b) { return are_close(a.x, b.x) && are_close(a.y, b.y) && are_close(a.z, b.z); }
+
+// ---------------------------------------------------------------------------------------------
+// PCG — include/random.hpp:29-101
+// ---------------------------------------------------------------------------------------------
+struct Pcg { uint64_t state, inc; };
+constexpr uint64_t PCG_MULT = 6364136223846793005ull;
+
+RT_DEV uint32_t pcg_random(Pcg &p) { // random.hpp:52-64
+  uint64_t old = p.state;
+  p.state = old * PCG_MULT + p.inc;
+  uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  uint32_t rot = (uint32_t)(old >> 59u);
+  return (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+}
+RT_DEV void pcg_init(Pcg &p, uint64_t init_state, uint64_t init_seq) { // random.hpp:41-47
+  p.state = 0;
+  p.inc = (init_seq << 1u) | 1u;
+  pcg_random(p);
+  p.state += init_state;
+  pcg_random(p);
+}
+// random.hpp:67-70: float(ran) / 2^32 (exact scaling; float(ran) rounds to nearest, may give 1.0f)
+RT_DEV float pcg_random_float(Pcg &p) { return (float)pcg_random(p) * 2.3283064365386963e-10f; }
+
+// LCG jump-ahead by n steps, O(log n) (Brown 1994).
+RT_DEV void pcg_advance(Pcg &p, uint64_t n) {
+  uint64_t acc_mult = 1, acc_plus = 0, cur_mult = PCG_MULT, cur_plus = p.inc;
+  while (n > 0) {
+    if (n & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    n >>= 1;
+  }
+  p.state = acc_mult * p.state + acc_plus;
+}
+
+RT_DEV uint64_t mix64(uint64_t z) { // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// Per-sample path stream (RT_RNG_PER_SAMPLE_STREAMS): depends only on (seq_number, global sample
+// index), so the image is identical for any GPU count.  Same derivation as oracle/rt_oracle.c.
+RT_DEV void sample_stream(Pcg &p, uint64_t seq_number, uint64_t global_sample) {
+  uint64_t init_state = mix64(global_sample ^ mix64(seq_number));
+  uint64_t init_seq = mix64(init_state);
+  pcg_init(p, init_state, init_seq);
+}
+
+// The AA generator is always PCG(42, 54) (ImageTracer ctor quirk, cameras.hpp:178-183); its state
+// after the constructor, advanced by 2k draws, gives sample k's jitter pair (cameras.hpp:232-233).
+RT_DEV void aa_jitter(uint64_t k, float &u, float &v) {
+  Pcg p;
+  pcg_init(p, 42ull, 54ull);
+  pcg_advance(p, 2 * k);
+  u = pcg_random_float(p);
+  v = pcg_random_float(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera — include/cameras.hpp:112-121, 133-137, 155-159, 200-208
+// ---------------------------------------------------------------------------------------------
+RT_DEV Ray camera_fire_ray(const Camera &cam, int width, int height, int col, int row, float u_pixel, float v_pixel) {
+  float u = ((float)col + u_pixel) / (float)width;
+  float v = 1.f - (((float)row + v_pixel) / (float)height);
+  float y = (1.f - u * 2.f) * cam.asp;
+  float z = -1.f + v * 2.f;
+  Ray r;
+  r.tmin = 1e-5f;
+  r.tmax = INF_F;
+  if (cam.kind == RT_CAMERA_PERSPECTIVE) {
+    r.o = mk3(-cam.distance, 0.f, 0.f);
+    r.d = mk3(cam.distance, y, z);
+  } else {
+    r.o = mk3(-1.f, y, z);
+    r.d = mk3(1.f, 0.f, 0.f);
+  }
+  return ray_transform(r, cam.fwd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shapes — include/shapes.hpp
+// ---------------------------------------------------------------------------------------------
+
+// Sphere::solve_ray_sphere — shapes.hpp:269-303.  Returns the number of valid roots (0..2).
+RT_DEV int solve_ray_sphere(const Ray &ray, float &ta, float &tb) {
+  float a = sqnorm3(ray.d);
+  float b = dot3(ray.o, ray.d);
+  float c = sqnorm3(ray.o) - 1.f;
+  float reduced_disc = b * b - a * c;
+  if (reduced_disc <= 0.f)
+    return 0;
+  float sq = sqrtf(reduced_disc);
+  float t1 = (-b - sq) / a;
+  float t2 = (-b + sq) / a;
+  if (t1 > t2) {
+    float tmp = t1;
+    t1 = t2;
+    t2 = tmp;
+  }
+  if (t1 < ray.tmin) {
+    if (t2 > ray.tmin && t2 < ray.tmax) {
+      ta = t2;
+      return 1;
+    }
+    return 0;
+  }
+  ta = t1;
+  if (t2 < ray.tmax) {
+    tb = t2;
+    return 2;
+  }
+  return 1;
+}
+
+// Plane::ray_intersection predicate — shapes.hpp:329-338
+RT_DEV bool solve_ray_plane(const Ray &ray, float &t) {
+  if (are_close(ray.d.z, 0.f))
+    return false;
+  float t_hit = -ray.o.z / ray.d.z;
+  if (t_hit < ray.tmin || t_hit > ray.tmax)
+    return false;
+  t = t_hit;
+  return true;
+}
+
+// What the renderers read from a HitRecord (shapes.hpp:65-96), plus the leaf-frame point from which
+// (u,v) is derived lazily (only pigments that read uv pay for atan2/acos).
+struct Hit {
+  int object; // index in World::objects, -1 = miss
+  int shape;
+  float t;
+  V3 point;  // world_point
+  V3 normal; // not normalised
+  V3 local;  // hit point in the standard shape's frame
+};
+
+// Shape::make_hit without uv — shapes.hpp:163-186, 254-256, 362
+RT_DEV void make_hit(const Scene &s, int shape, const Ray &ray_local, float t, V3 &point, V3 &normal, V3 &local) {
+  V3 p = add3(ray_local.o, lscale3(t, ray_local.d)); // Ray::at — cameras.hpp:62
+  V3 n = (s.shape_kind[shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
+  float sign = copysignf(1.0f, -(dot3(n, ray_local.d)));
+  n = scale3(n, sign);
+  local = p;
+  point = hom_point(s.shape_fwd + 12 * shape, p);
+  normal = hom_transposed(s.shape_inv + 12 * shape, n); // Transformation * Normal — geometry.hpp:506
+}
+
+// Sphere::calculate_uv / Plane::calculate_uv — shapes.hpp:259-266, 365-367
+RT_DEV void shape_uv(const Scene &s, int shape, V3 p, float &u, float &v) {
+  if (s.shape_kind[shape] == RT_SHAPE_SPHERE) {
+    float uu = atan2f(p.y, p.x) / (2.f * PI_F);
+    if (uu < 0.f)
+      uu = uu + 1.f;
+    u = uu;
+    v = acosf(p.z) / PI_F;
+  } else {
+    u = p.x - floorf(p.x);
+    v = p.y - floorf(p.y);
+  }
+}
+
+// Sphere::is_point_inside / Plane::is_point_inside — shapes.hpp:245-250, 353-358
+RT_DEV bool shape_is_point_inside(const Scene &s, int shape, V3 point_world) {
+  V3 p = hom_point(s.shape_inv + 12 * shape, point_world);
+  return (s.shape_kind[shape] == RT_SHAPE_SPHERE) ? (sqnorm3(p) < 1.f) : (p.z < 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSG without a heap — include/shapes.hpp:396-490
+// ---------------------------------------------------------------------------------------------
+
+// CSGObject::is_point_inside of a whole subtree, as an RPN program over its leaves
+// (shapes.hpp:438-457).  `p` is in the frame the subtree's root object lives in.
+RT_DEV bool csg_prog_inside(const Scene &s, int begin, int end, V3 p) {
+  uint32_t bits = 0; // boolean stack, top = bit 0
+  for (int e = begin; e < end; ++e) {
+    const CsgProgEntry pe = s.csg_prog[e];
+    if (!pe.is_op) {
+      V3 q = p;
+      for (int k = 0; k < pe.path_len; ++k)
+        q = hom_point(s.csg_inv + 12 * s.csg_prog_path[pe.path_begin + k], q);
+      bits = (bits << 1) | (shape_is_point_inside(s, pe.arg, q) ? 1u : 0u);
+    } else {
+      const bool in2 = bits & 1u, in1 = (bits >> 1) & 1u;
+      bool r;
+      switch (pe.arg) {
+      case RT_CSG_UNION: r = in1 || in2; break;
+      case RT_CSG_INTERSECTION: r = in1 && in2; break;
+      case RT_CSG_DIFFERENCE: r = in1 && !in2; break;
+      default: r = in1 || in2; break; // FUSION
+      }
+      bits = ((bits >> 2) << 1) | (r ? 1u : 0u);
+    }
+  }
+  return bits & 1u;
+}
+
+// CSGObject::hit_on_obj1_valid / hit_on_obj2_valid — shapes.hpp:460-490
+RT_DEV bool csg_hit_valid(int op, int side, bool inside_sibling) {
+  switch (op) {
+  case RT_CSG_UNION: return true;
+  case RT_CSG_INTERSECTION: return inside_sibling;
+  case RT_CSG_DIFFERENCE: return side == 0 ? !inside_sibling : inside_sibling;
+  default: return !inside_sibling; // FUSION
+  }
+}
+
+// CSGObject::ray_intersection = front of all_ray_intersections (shapes.hpp:396-435), evaluated leaf
+// by leaf: a leaf hit survives iff it passes the validity rule of every CSG node on its way to the
+// root, each tested with the hit point expressed in that node's frame — the same chain of
+// transformations, in the same order, as the recursive reference.  Ties in t between leaves go to
+// the later leaf (merge_ordered_vectors takes from the second list on ties, shapes.hpp:47-52).
+RT_DEV bool csg_ray_intersection(const Scene &s, const CsgTop &top, const Ray &ray_world, Hit &best) {
+  bool found = false;
+  for (int li = top.leaf_begin; li < top.leaf_end; ++li) {
+    const CsgLeaf leaf = s.csg_leaf[li];
+    Ray ray = ray_world;
+    for (int k = 0; k < leaf.path_len; ++k)
+      ray = ray_transform(ray, s.csg_inv + 12 * s.csg_path[leaf.path_begin + k].node);
+    const Ray ray_parent = ray;
+    ray = ray_transform(ray_parent, s.shape_inv + 12 * leaf.shape);
+    float ts[2];
+    int nt;
+    if (s.shape_kind[leaf.shape] == RT_SHAPE_SPHERE) {
+      nt = solve_ray_sphere(ray, ts[0], ts[1]);
+    } else {
+      nt = solve_ray_plane(ray, ts[0]) ? 1 : 0;
+    }
+    bool first_of_leaf = true;
+    for (int i = 0; i < nt; ++i) {
+      const float t = ts[i];
+      // Sphere::all_ray_intersections re-checks the open interval (shapes.hpp:236)
+      if (s.shape_kind[leaf.shape] == RT_SHAPE_SPHERE && !(t > ray.tmin && t < ray.tmax))
+        continue;
+      V3 point, normal, local;
+      make_hit(s, leaf.shape, ray, t, point, normal, local);
+      bool valid = true;
+      for (int k = leaf.path_len - 1; k >= 0 && valid; --k) {
+        const CsgStep st = s.csg_path[leaf.path_begin + k];
+        const int *range = s.csg_prog_range + 4 * st.node + 2 * (1 - st.side);
+        const bool inside = csg_prog_inside(s, range[0], range[1], point);
+        valid = csg_hit_valid(s.csg_op[st.node], st.side, inside);
+        if (valid) { // HitRecord::transform_in_place — shapes.hpp:91-95
+          point = hom_point(s.csg_fwd + 12 * st.node, point);
+          normal = hom_transposed(s.csg_inv + 12 * st.node, normal);
+        }
+      }
+      if (!valid)
+        continue;
+      const bool better = !found || (first_of_leaf ? (t <= best.t) : (t < best.t));
+      if (better) {
+        found = true;
+        best.t = t;
+        best.shape = leaf.shape;
+        best.point = point;
+        best.normal = normal;
+        best.local = local;
+        best.object = top.object;
+      }
+      first_of_leaf = false;
+    }
+  }
+  return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// World — include/shapes.hpp:520-604
+// ---------------------------------------------------------------------------------------------
+
+// Wave-uniform read of a scan record field: the address is the same in every lane, so the load
+// can be scalar (s_load) and the operand lives in SGPRs.
+typedef const __attribute__((address_space(4))) float *ConstF;
+RT_DEV ConstF scan_inv(const ScanRec *recs, int i) { return (ConstF)(uintptr_t)(recs[i].inv); }
+
+// Front hit t of a top-level sphere (Sphere::ray_intersection, shapes.hpp:206-221)
+template <typename P> RT_DEV bool sphere_front_t(P inv, const Ray &ray_world, float &t) {
+  Ray ray = ray_transform(ray_world, inv);
+  float tb;
+  return solve_ray_sphere(ray, t, tb) > 0;
+}
+template <typename P> RT_DEV bool plane_front_t(P inv, const Ray &ray_world, float &t) {
+  Ray ray = ray_transform(ray_world, inv);
+  return solve_ray_plane(ray, t);
+}
+
+// World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
+// (strict `<` in insertion order).  The full record is built for the winner only.
+RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
+  float best_t = INF_F;
+  int best_obj = 0x7fffffff, best_shape = -1;
+  for (int i = 0; i < s.n_spheres; ++i) {
+    float t;
+    if (sphere_front_t(scan_inv(s.spheres, i), ray, t) && t < best_t) {
+      best_t = t;
+      best_obj = s.spheres[i].object;
+      best_shape = s.spheres[i].shape;
+    }
+  }
+  for (int i = 0; i < s.n_planes; ++i) {
+    float t;
+    const int obj = s.planes[i].object;
+    if (plane_front_t(scan_inv(s.planes, i), ray, t) && (t < best_t || (t == best_t && obj < best_obj))) {
+      best_t = t;
+      best_obj = obj;
+      best_shape = s.planes[i].shape;
+    }
+  }
+  Hit h;
+  h.object = -1;
+  h.shape = -1;
+  h.t = 0.f;
+  h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+  bool csg_won = false;
+  for (int i = 0; i < s.n_csg_tops; ++i) {
+    const CsgTop top = s.csg_tops[i];
+    Hit c;
+    if (csg_ray_intersection(s, top, ray, c) && (c.t < best_t || (c.t == best_t && c.object < best_obj))) {
+      best_t = c.t;
+      best_obj = c.object;
+      h = c;
+      csg_won = true;
+    }
+  }
+  if (best_shape < 0 && !csg_won)
+    return h;
+  if (!csg_won) {
+    Ray local = ray_transform(ray, s.shape_inv + 12 * best_shape);
+    h.object = best_obj;
+    h.shape = best_shape;
+    h.t = best_t;
+    make_hit(s, best_shape, local, best_t, h.point, h.normal, h.local);
+  }
+  return h;
+}
+
+// World::on_off_ray_intersection — shapes.hpp:567-578 (only the boolean is used, renderers.hpp:62-69)
+RT_DEV bool world_any_hit(const Scene &s, const Ray &ray) {
+  bool hit = false;
+  for (int i = 0; i < s.n_spheres && !hit; ++i) {
+    float t;
+    hit = sphere_front_t(scan_inv(s.spheres, i), ray, t);
+  }
+  for (int i = 0; i < s.n_planes && !hit; ++i) {
+    float t;
+    hit = plane_front_t(scan_inv(s.planes, i), ray, t);
+  }
+  for (int i = 0; i < s.n_csg_tops && !hit; ++i) {
+    Hit c;
+    hit = csg_ray_intersection(s, s.csg_tops[i], ray, c);
+  }
+  return hit;
+}
+
+// World::offset_if_visible — shapes.hpp:584-603
+RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 normal, V3 &in_dir_out) {
+  V3 in_dir = sub3(surface, viewer);
+  Ray in_ray;
+  in_ray.o = viewer;
+  in_ray.d = in_dir;
+  in_ray.tmin = 1e-5f;
+  in_ray.tmax = INF_F;
+  if (dot3(in_dir, normal) > 0.f)
+    return false;
+  for (int i = 0; i < s.n_spheres; ++i) {
+    float t;
+    if (sphere_front_t(scan_inv(s.spheres, i), in_ray, t) && t < 1.f) {
+      const int shape = s.spheres[i].shape;
+      Ray local = ray_transform(in_ray, s.shape_inv + 12 * shape);
+      V3 p = hom_point(s.shape_fwd + 12 * shape, add3(local.o, lscale3(t, local.d)));
+      if (!point_is_close(p, surface))
+        return false;
+    }
+  }
+  for (int i = 0; i < s.n_planes; ++i) {
+    float t;
+    if (plane_front_t(scan_inv(s.planes, i), in_ray, t) && t < 1.f) {
+      const int shape = s.planes[i].shape;
+      Ray local = ray_transform(in_ray, s.shape_inv + 12 * shape);
+      V3 p = hom_point(s.shape_fwd + 12 * shape, add3(local.o, lscale3(t, local.d)));
+      if (!point_is_close(p, surface))
+        return false;
+    }
+  }
+  for (int i = 0; i < s.n_csg_tops; ++i) {
+    Hit c;
+    if (csg_ray_intersection(s, s.csg_tops[i], in_ray, c) && c.t < 1.f && !point_is_close(c.point, surface))
+      return false;
+  }
+  in_dir_out = in_dir;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Materials — include/materials.hpp
+// ---------------------------------------------------------------------------------------------
+
+// UniformPigment / CheckeredPigment / ImagePigment::operator() — materials.hpp:64, 85-94, 120-137
+RT_DEV V3 pigment_eval(const Scene &s, uint32_t pg, float u, float v) {
+  const int kind = s.pigment_kind[pg];
+  if (kind == RT_PIGMENT_CHECKERED) {
+    float subinterval = 1.f / (float)s.pigment_n_intervals[pg]; // materials.hpp:81
+    int col = (int)(u / subinterval);
+    int row = (int)(v / subinterval);
+    return ((col + row) % 2 == 0) ? ld3(s.pigment_color1 + 3 * pg) : ld3(s.pigment_color2 + 3 * pg);
+  }
+  if (kind == RT_PIGMENT_IMAGE) {
+    int w = s.pigment_tex_width[pg], h = s.pigment_tex_height[pg];
+    int col = (int)(u * (float)w);
+    int row = (int)(v * (float)h);
+    if (col >= w) col = w - 1;
+    if (row >= h) row = h - 1;
+    return ld3(s.texels + 3 * ((size_t)s.pigment_tex_offset[pg] + (size_t)row * (size_t)w + (size_t)col));
+  }
+  return ld3(s.pigment_color1 + 3 * pg);
+}
+
+// (u,v) of a hit, computed only when one of the material's pigments reads it
+RT_DEV void hit_uv(const Scene &s, const Hit &h, uint32_t material, float &u, float &v) {
+  u = 0.f;
+  v = 0.f;
+  if (s.material_needs_uv[material])
+    shape_uv(s, h.shape, h.local, u, v);
+}
+
+// ONB(Vec) (Duff et al.) — geometry.hpp:591-599
+RT_DEV void onb_from_e3(V3 e3, V3 &e1, V3 &e2) {
+  float sign = copysignf(1.f, e3.z);
+  const float a = -1.f / (sign + e3.z);
+  const float b = e3.x * e3.y * a;
+  e1 = mk3(1.f + sign * e3.x * e3.x * a, sign * b, -sign * e3.x);
+  e2 = mk3(b, sign + e3.y * e3.y * a, -e3.y);
+}
+
+// DiffusiveBRDF::scatter_ray direction given the normalised normal — materials.hpp:199-211,
+// PCG::random_phong(1) — random.hpp:75-84
+RT_DEV V3 diffuse_scatter_dir(V3 e3, Pcg &pcg) {
+  V3 e1, e2;
+  onb_from_e3(e3, e1, e2);
+  float x = pcg_random_float(pcg);
+  float theta = acosf(powf(x, 1.f / 2.f));
+  float phi = pcg_random_float(pcg) * 2 * PI_F;
+  float st = sinf(theta), ct = cosf(theta);
+  V3 a = scale3(scale3(e1, st), cosf(phi));
+  V3 b = scale3(scale3(e2, st), sinf(phi));
+  V3 c = scale3(e3, ct);
+  return add3(add3(a, b), c);
+}
+
+// SpecularBRDF::scatter_ray direction — materials.hpp:252-261
+RT_DEV V3 specular_scatter_dir(V3 in_dir, V3 normal) {
+  in_dir = normalized3(in_dir);
+  V3 n = normalized3(normal);
+  return sub3(in_dir, scale3(scale3(n, 2.f), dot3(n, in_dir)));
+}
+
+} // namespace rtd

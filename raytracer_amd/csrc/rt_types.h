@@ -1,0 +1,112 @@
+// rt_types.h — device-side layout of a flattened World (see include/raytracer_amd.h for the ABI).
+//
+// HBM layout, chosen for how the tracing loop reads it:
+//  * Top-level spheres / planes ("scan lists"): one 64-byte record per object, read WAVE-UNIFORMLY
+//    (every lane of a wave tests the same object at the same time) through scalar loads, in
+//    World::objects order.  Record = inverse hom matrix (12 f32) + object index + shape index.
+//  * Per-shape tables (fwd / inv / kind / material), pigments, materials, lights: gathered per lane,
+//    once per ray, for the closest hit only.
+//  * CSG: per top-level CSG object a left-to-right leaf list; per leaf the chain of CSG nodes from
+//    the root down to its parent; per (node, side) an RPN "point inside sibling?" program.
+#pragma once
+#include <stdint.h>
+
+namespace rtd {
+
+struct ScanRec {       // 64 B, 64-B aligned: one top-level Sphere or Plane
+  float inv[12];       // Object::transformation.inverse_hom_matrix
+  int32_t object;      // index in World::objects
+  int32_t shape;       // index in the shape tables
+  int32_t pad0, pad1;
+};
+
+struct CsgTop {        // one top-level CSGObject
+  int32_t object;      // index in World::objects
+  int32_t leaf_begin;  // range in csg_leaf[]
+  int32_t leaf_end;
+  int32_t pad;
+};
+
+struct CsgLeaf {       // one Sphere/Plane leaf below a top-level CSG object (left-to-right order)
+  int32_t shape;
+  int32_t path_begin;  // range in csg_path[]: root ... parent of the leaf
+  int32_t path_len;
+  int32_t pad;
+};
+
+struct CsgStep {       // one CSG node on a root->leaf chain
+  int32_t node;        // index in the node tables
+  int32_t side;        // 0: the chain continues into object1, 1: into object2
+};
+
+struct CsgProgEntry {  // RPN program "is point inside this subtree?"
+  int32_t is_op;       // 0: leaf, 1: boolean op of the two previous results
+  int32_t arg;         // leaf: shape index; op: RT_CSG_*
+  int32_t path_begin;  // leaf: range in csg_prog_path[] (CSG nodes from the subtree root to the leaf's parent)
+  int32_t path_len;
+};
+
+struct Scene {
+  // scan lists
+  const ScanRec *spheres; int32_t n_spheres;
+  const ScanRec *planes;  int32_t n_planes;
+  const CsgTop *csg_tops; int32_t n_csg_tops;
+  int32_t n_objects;
+  // shape tables
+  const float *shape_fwd;         // [n_shapes][12]
+  const float *shape_inv;         // [n_shapes][12]
+  const uint8_t *shape_kind;
+  const uint32_t *shape_material;
+  // CSG tables
+  const CsgLeaf *csg_leaf;
+  const CsgStep *csg_path;
+  const float *csg_fwd;           // [n_nodes][12]
+  const float *csg_inv;
+  const uint8_t *csg_op;
+  const int32_t *csg_prog_range;  // [n_nodes][2 sides][2] begin,end in csg_prog[]
+  const CsgProgEntry *csg_prog;
+  const int32_t *csg_prog_path;
+  // materials / pigments / lights
+  const uint8_t *material_brdf;
+  const uint32_t *material_brdf_pigment;
+  const uint32_t *material_emission_pigment;
+  const uint8_t *material_needs_uv; // 1 if either pigment of the material reads (u,v)
+  const uint8_t *pigment_kind;
+  const float *pigment_color1;
+  const float *pigment_color2;
+  const int32_t *pigment_n_intervals;
+  const uint32_t *pigment_tex_offset;
+  const int32_t *pigment_tex_width;
+  const int32_t *pigment_tex_height;
+  const float *texels;
+  const float *light_point;
+  const float *light_color;
+  const float *light_radius;
+  int32_t n_lights;
+};
+
+struct Camera {
+  float fwd[12];
+  float asp;
+  float distance;
+  int32_t kind;
+};
+
+struct RenderParams {
+  Camera cam;
+  int32_t width, height, spp_edge, mode;
+  int32_t n_rays, roulette, max_depth, max_mirror_bounces;
+  uint64_t seq_number;
+  float background[3];
+  float ambient[3];
+  int32_t band_rows, band_stride, band_offset, n_local_rows;
+  uint64_t n_samples;          // n_local_rows * width * spp_edge^2
+  float *samples_out;          // [n_samples][3] (== framebuffer when spp_edge == 1)
+  unsigned long long *counters; // [0] next sample, [1] rays, [2] capped samples
+  // path mode: per-lane DFS stack in HBM, SoA: word w of level l of lane g at stack[(l*STACK_WORDS + w)*n_lanes + g]
+  float *stack;
+  uint32_t n_lanes;
+  int32_t stack_levels;
+};
+
+} // namespace rtd

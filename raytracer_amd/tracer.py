@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's ImageTracer / Renderer interface over the C-ABI.
+
+    reference (C++)                                     here
+    -----------------------------------------------     ------------------------------------------
+    World                       include/shapes.hpp:520   DeviceWorld(FlatScene, device)
+    ImageTracer{image,camera,spp}   cameras.hpp:166-187  GpuImageTracer(width, height, camera, spp_edge)
+    build_renderer(mode_cfg, world) raytracer.cpp:333    RenderMode("path", n_rays=..., ...)
+    tracer.fire_all_rays(renderer)  cameras.hpp:221      tracer.fire_all_rays(world, mode) -> image
+
+Every call goes through libraytracer_amd.so; nothing here computes pixels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi
+from .lib import check, dll
+from .scene import Camera, FlatScene
+
+
+@dataclass
+class RenderMode:
+    """ModeCfg + PathCfg (reference src/raytracer.cpp:40-51) and the constants build_renderer passes."""
+    mode: str = "flat"
+    n_rays: int = 10           # --n_rays
+    roulette: int = 3          # --roulette
+    max_depth: int = 5         # --max-depth
+    seq_number: int = 54       # --seq-number
+    background: tuple = (0.0, 0.0, 0.0)          # BLACK, raytracer.cpp:337,348,352
+    ambient: tuple = (0.1, 0.1, 0.1)             # DARK_GREY, renderers.hpp:103
+    max_mirror_bounces: int = 64                 # the reference has no cap (renderers.hpp:129-152)
+
+
+@dataclass
+class RowBands:
+    """Rows of the image one call renders: local row lr -> (lr // band_rows) * band_stride + band_offset + lr % band_rows."""
+    band_rows: int
+    band_stride: int
+    band_offset: int
+    n_local_rows: int
+
+    @staticmethod
+    def whole(height: int) -> "RowBands":
+        return RowBands(height, height, 0, height)
+
+    @staticmethod
+    def cyclic(height: int, rank: int, world: int, band_rows: int = 16) -> "RowBands":
+        """16-row bands dealt round-robin to ranks: path cost is strongly row dependent."""
+        n = sum(min(band_rows, height - start) for start in range(rank * band_rows, height, world * band_rows))
+        return RowBands(band_rows, band_rows * world, band_rows * rank, n)
+
+    def image_rows(self) -> np.ndarray:
+        lr = np.arange(self.n_local_rows)
+        return (lr // self.band_rows) * self.band_stride + self.band_offset + lr % self.band_rows
+
+
+class DeviceWorld:
+    """A flattened World resident in HBM (rt_scene*)."""
+
+    def __init__(self, scene: FlatScene, device: int = 0):
+        self.scene = scene
+        self.device = device
+        self._handle = C.c_void_p()
+        desc = scene.desc()
+        check(dll().rt_scene_create(C.byref(desc), device, C.byref(self._handle)))
+
+    def close(self):
+        if self._handle:
+            dll().rt_scene_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._handle:
+            raise RuntimeError("DeviceWorld is closed")
+        return self._handle
+
+    # -- batch operators (parity entry points) ---------------------------------------------------
+    def ray_intersection(self, rays: np.ndarray) -> np.ndarray:
+        """World::ray_intersection for a batch (rays: abi.RAY_DTYPE) -> abi.HIT_DTYPE."""
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)
+        check(dll().rt_trace_rays(self.handle, rays.ctypes.data, len(rays), hits.ctypes.data))
+        return hits
+
+    def offset_if_visible(self, viewer, surface, normal) -> np.ndarray:
+        viewer = np.ascontiguousarray(viewer, dtype=np.float32).reshape(-1, 3)
+        surface = np.ascontiguousarray(surface, dtype=np.float32).reshape(-1, 3)
+        normal = np.ascontiguousarray(normal, dtype=np.float32).reshape(-1, 3)
+        vis = np.zeros(len(viewer), dtype=np.uint8)
+        check(dll().rt_offset_if_visible(self.handle, viewer.ctypes.data, surface.ctypes.data, normal.ctypes.data,
+                                         len(viewer), vis.ctypes.data))
+        return vis
+
+
+def aa_jitter(sample_index, device: int = 0):
+    k = np.ascontiguousarray(sample_index, dtype=np.uint64)
+    u = np.zeros(len(k), dtype=np.float32)
+    v = np.zeros(len(k), dtype=np.float32)
+    check(dll().rt_aa_jitter(device, k.ctypes.data, len(k), u.ctypes.data, v.ctypes.data))
+    return u, v
+
+
+class GpuImageTracer:
+    """ImageTracer with the per-pixel loop on the GPU."""
+
+    def __init__(self, width: int, height: int, camera: Camera, samples_per_pixel_edge: int = 1):
+        if width <= 0 or height <= 0:
+            raise ValueError("HdrImage dimensions must be positive")  # colors.hpp:386-389
+        self.width, self.height = width, height
+        self.camera = camera
+        self.samples_per_pixel_edge = samples_per_pixel_edge
+        self.last_stats: abi.rt_stats | None = None
+
+    def make_cfg(self, mode: RenderMode, rows: RowBands | None = None) -> abi.rt_render_cfg:
+        rows = rows or RowBands.whole(self.height)
+        cfg = abi.rt_render_cfg()
+        cfg.width, cfg.height, cfg.spp_edge = self.width, self.height, self.samples_per_pixel_edge
+        cfg.mode = abi.MODES[mode.mode]
+        cfg.n_rays, cfg.roulette, cfg.max_depth, cfg.seq_number = mode.n_rays, mode.roulette, mode.max_depth, mode.seq_number
+        cfg.background[:] = mode.background
+        cfg.ambient[:] = mode.ambient
+        cfg.max_mirror_bounces = mode.max_mirror_bounces
+        cfg.rng_mode = abi.RT_RNG_PER_SAMPLE_STREAMS
+        cfg.band_rows, cfg.band_stride, cfg.band_offset = rows.band_rows, rows.band_stride, rows.band_offset
+        cfg.n_local_rows = rows.n_local_rows
+        return cfg
+
+    def fire_all_rays(self, world: DeviceWorld, mode: RenderMode, rows: RowBands | None = None, out=None,
+                      stream=None, want_stats: bool = True):
+        """Renders this tracer's rows.
+
+        out=None      -> numpy float32 [n_local_rows, W, 3] (device framebuffer + D2H inside the library)
+        out=<tensor>  -> a CUDA/HIP torch tensor of that shape on world.device, filled in place (stays in HBM);
+                         `stream` = a raw hipStream_t (int) or None for torch's current stream.
+        """
+        cfg = self.make_cfg(mode, rows)
+        cam = self.camera.to_abi()
+        stats = abi.rt_stats()
+        stats_p = C.byref(stats) if want_stats else None
+        if out is None:
+            img = np.empty((cfg.n_local_rows, self.width, 3), dtype=np.float32)
+            check(dll().rt_render_host(world.handle, C.byref(cam), C.byref(cfg), img.ctypes.data, stats_p))
+            self.last_stats = stats if want_stats else None
+            return img
+        import torch
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                and tuple(out.shape) == (cfg.n_local_rows, self.width, 3) and out.device.index == world.device):
+            raise ValueError("out must be a contiguous float32 CUDA tensor [n_local_rows, W, 3] on the world's device")
+        if stream is None:
+            stream = torch.cuda.current_stream(out.device).cuda_stream
+        check(dll().rt_render(world.handle, C.byref(cam), C.byref(cfg), out.data_ptr(), stream, stats_p))
+        self.last_stats = stats if want_stats else None
+        return out
