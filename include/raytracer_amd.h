@@ -244,6 +244,13 @@ RT_API rt_status rt_offset_if_visible(rt_scene *scene, const float *viewer, cons
  * Host pointers; parity entry point for the exact-jitter claim. */
 RT_API rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float *u_out, float *v_out);
 
+/* Batch BRDF::scatter_ray directions: DiffusiveBRDF (include/materials.hpp:199-211, consumes two
+ * draws of the given PCG via PCG::random_phong(1), include/random.hpp:75-84) or SpecularBRDF
+ * (include/materials.hpp:252-261, consumes none).  pcg: [n][2] = {state, inc} in/out; in_dir,
+ * normal, dir_out: [n][3].  Host pointers; parity entry point. */
+RT_API rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const float *in_dir,
+                                 const float *normal, size_t n, float *dir_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,4 +542,32 @@ rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float
   return RT_OK;
 }
 
+rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const float *in_dir, const float *normal, size_t n,
+                          float *dir_out) {
+  if (brdf_kind > RT_BRDF_SPECULAR || (n && (!pcg || !in_dir || !normal || !dir_out)))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_scatter_rays: bad argument");
+  if (n == 0)
+    return RT_OK;
+  RT_HIP(hipSetDevice(device));
+  uint64_t *d_pcg = nullptr;
+  float *d_f = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_pcg), 2 * n * sizeof(uint64_t)));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_f), 9 * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(d_pcg, pcg, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_f, in_dir, 3 * n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_f + 3 * n, normal, 3 * n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rtd::k_scatter_rays, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, brdf_kind, d_pcg,
+                       d_f, d_f + 3 * n, n, d_f + 6 * n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(dir_out, d_f + 6 * n, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(pcg, d_pcg, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_pcg);
+  (void)hipFree(d_f);
+  if (e != hipSuccess)
+    return fail(RT_ERR_HIP, std::string("rt_scatter_rays: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
 } // extern "C"

@@ -504,7 +504,9 @@ RT_DEV V3 diffuse_scatter_dir(V3 e3, Pcg &pcg) {
   V3 e1, e2;
   onb_from_e3(e3, e1, e2);
   float x = pcg_random_float(pcg);
-  float theta = acosf(powf(x, 1.f / 2.f));
+  // pow(x, 1.f/(n+1)) with n = 1 is x^(1/2): sqrtf is correctly rounded, which is what glibc's powf
+  // returns for this exponent (the device powf is not), so theta tracks the reference more closely.
+  float theta = acosf(sqrtf(x));
   float phi = pcg_random_float(pcg) * 2 * PI_F;
   float st = sinf(theta), ct = cosf(theta);
   V3 a = scale3(scale3(e1, st), cosf(phi));

