@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — path-mode throughput of the MI355X tracing backend on the synthetic N-sphere scene.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = one full frame: BASELINE.json's metric config, 1920x1080, AA=4 (16 spp), --mode path,
+n_rays=10, roulette=3, max-depth=5, on the synthetic 4096-random-sphere + floor + sky scene of
+raytracer_amd/synth.py.  With N ranks the frame's rows are dealt in 16-row cyclic bands (strong scaling: the
+frame is fixed), each rank renders its bands into HBM and rank 0 gathers them over RCCL.  The scene and the
+framebuffers are resident in HBM before the timed region.  A ray = one World::ray_intersection query.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def flops_per_ray(n_spheres_top: int, n_planes_top: int) -> float:
+    """Algorithmic fp32 flops of one closest-hit query + shading, counted on the reference's arithmetic as
+    written: 52 per sphere test that misses (33 ray->object frame + 19 up to the discriminant),
+    +7 for a sphere that is hit (the sky sphere always is), 35 per plane, 54 for the winner's hit record,
+    ~75 for scatter + shading."""
+    return 52.0 * n_spheres_top + 7.0 + 35.0 * n_planes_top + 54.0 + 75.0
+
+
+def cpu_baseline(scene, text, args):
+    """Times the CPU on a bounded sample of the same workload: the synthetic scene at a small resolution.
+    kind "reference": the unmodified reference (oracle/_ref/rt_ref, single-threaded by construction); the
+    ray count comes from the CPU restatement run on the same configuration with the reference's serial PCG
+    (it reproduces the reference bit for bit, so it traces exactly the same rays).  kind "port": only the
+    restatement is timed (when the reference binary is not there)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from raytracer_amd import abi
+    w, h, aa = args.cpu_width, args.cpu_height, 1
+    cfg = O.make_cfg(w, h, "path", spp_edge=aa, n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth,
+                     seq_number=54, rng_mode=abi.RT_RNG_SERIAL_REFERENCE)
+    t0 = time.perf_counter()
+    _, stats = O.render(scene, cfg)
+    port_s = time.perf_counter() - t0
+    sample = f"{scene.count('n_objects')}-object synthetic scene, path {args.n_rays}/{args.roulette}/{args.max_depth}, {w}x{h} AA=1 ({stats.rays} rays)"
+    out = {"value": stats.rays / port_s / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample,
+           "seconds": port_s}
+    if os.path.exists(O.REF_BIN):
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "scene.txt")
+            with open(path, "w") as f:
+                f.write(text)
+            res = subprocess.run([O.REF_BIN, "render", path, "-o", os.path.join(tmp, "o.pfm"), "--mode", "path", "--width", str(w),
+                                  "--height", str(h), "--aa", str(aa), "--n_rays", str(args.n_rays), "--roulette", str(args.roulette),
+                                  "--max-depth", str(args.max_depth), "--seq", "54"], capture_output=True, text=True, check=True)
+            ref_s = json.loads(res.stdout)["elapsed_s"]
+        out.update({"value": stats.rays / ref_s / 1e6, "kind": "reference", "seconds": ref_s,
+                    "port_value": stats.rays / port_s / 1e6})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--aa", type=int, default=4)
+    ap.add_argument("--spheres", type=int, default=4096)
+    ap.add_argument("--n_rays", type=int, default=10)
+    ap.add_argument("--roulette", type=int, default=3)
+    ap.add_argument("--max-depth", dest="max_depth", type=int, default=5)
+    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=48)
+    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.dist import gather_rows, max_local_rows, rank_rows
+    from raytracer_amd.synth import synthetic_scene
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    scene, text = synthetic_scene(args.spheres)
+    world = DeviceWorld(scene, local_rank)
+    tracer = GpuImageTracer(args.width, args.height, scene.camera, args.aa)
+    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54)
+    rows = rank_rows(args.height, rank, world_size)
+    local = torch.empty((rows.n_local_rows, args.width, 3), dtype=torch.float32, device=device)
+    full = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
+    padded = parts = None
+    if world_size > 1:
+        padded = torch.empty((max_local_rows(args.height, world_size), args.width, 3), dtype=torch.float32, device=device)
+        parts = [torch.empty_like(padded) for _ in range(world_size)] if rank == 0 else None
+
+    def step(want_stats=False):
+        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=want_stats)
+        gather_rows(local, args.height, full, padded=padded, parts=parts)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+
+    # One stats pass (untimed): the ray count of a frame is deterministic (streams depend only on the sample index)
+    step(want_stats=True)
+    rays_local = int(tracer.last_stats.rays)
+    samples_local = int(tracer.last_stats.samples)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()  # torch's current stream == the stream rt_render launches on
+        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
+        ev[k][1].record()
+        gather_rows(local, args.height, full, padded=padded, parts=parts)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+    r = torch.tensor([rays_local, samples_local], dtype=torch.int64, device=device)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed, kernel_ms_max = float(t[0]), float(t[1])
+    rays_total, samples_total = int(r[0]), int(r[1])
+
+    if rank == 0:
+        n_sph_top = args.spheres + 1  # + the sky sphere
+        f_ray = flops_per_ray(n_sph_top, 1)
+        # dominant kernel = k_render_path on rank 0's share; achieved = algorithmic flops of ITS rays / ITS duration
+        achieved = rays_local * f_ray / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "path-mode Mrays/s (frame ms in ms_per_step), 1920x1080 AA=4",
+            "value": rays_total * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.spheres}-random-sphere + floor + sky scene, --mode path, "
+                                   f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "
+                                   f"max-depth={args.max_depth}, seq-number=54",
+                       "objects": scene.count("n_objects"), "samples_per_frame": samples_total, "rays_per_frame": rays_total,
+                       "rays_per_sample": rays_total / max(samples_total, 1),
+                       "parallelism": f"row-bands16x{world_size}" if world_size > 1 else "single"},
+            "kernel_ms_per_step_max_rank": kernel_ms_max,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "rtd::k_render_path", "flops_per_ray": f_ray, "rays_per_launch": rays_local,
+                         "kernel_ms": kernel_ms},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, text, args)
+        if args.save_pfm:
+            img = full.cpu().numpy()
+            with open(args.save_pfm, "wb") as f:
+                f.write(b"PF\n%d %d\n-1.0\n" % (args.width, args.height))
+                f.write(img[::-1].astype("<f4").tobytes())
+        print(json.dumps(out), flush=True)
+    world.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Row-band sharding of one frame over the ranks of one node, and the gather to rank 0.
+
+The path shards by pixel rows with no exchange while rendering (every pixel sample is independent and its
+random stream depends only on its global index), so the only collective is one gather of the finished
+bands: each rank sends its compact [n_local_rows, W, 3] buffer to rank 0 over RCCL
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests), rank 0 scatters the rows into the
+row-major HdrImage layout.  Bands are 16 rows dealt round-robin, because path-mode cost is strongly row
+dependent (sky rows cost ~1 ray per sample, object rows hundreds).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .tracer import RowBands
+
+BAND_ROWS = 16
+
+
+def rank_rows(height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> RowBands:
+    return RowBands.cyclic(height, rank, world, band_rows)
+
+
+def max_local_rows(height: int, world: int, band_rows: int = BAND_ROWS) -> int:
+    return max(rank_rows(height, r, world, band_rows).n_local_rows for r in range(world))
+
+
+def gather_rows(local: torch.Tensor, height: int, full_out: torch.Tensor | None, band_rows: int = BAND_ROWS,
+                padded: torch.Tensor | None = None, parts: list | None = None):
+    """Gathers every rank's band buffer to rank 0 and assembles the image there.
+
+    local:    [n_local_rows, W, 3] float32 on this rank's device
+    full_out: [height, W, 3] on rank 0 (ignored elsewhere)
+    padded / parts: optional preallocated staging ([max_rows, W, 3]; on rank 0 a list of `world` such
+                    tensors) so that a timed loop allocates nothing.
+    Returns full_out on rank 0, None elsewhere.  With world size 1 it is a copy.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        full_out.copy_(local)
+        return full_out
+    max_rows = max_local_rows(height, world, band_rows)
+    if padded is None:
+        padded = torch.empty((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]].copy_(local)
+    if rank == 0:
+        if parts is None:
+            parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.gather(padded, gather_list=parts, dst=0)
+        for r in range(world):
+            rows = rank_rows(height, r, world, band_rows)
+            idx = torch.as_tensor(rows.image_rows(), device=full_out.device, dtype=torch.long)
+            full_out.index_copy_(0, idx, parts[r][: rows.n_local_rows])
+        return full_out
+    dist.gather(padded, gather_list=None, dst=0)
+    return None

@@ -58,6 +58,15 @@ def identity() -> Transformation:
     return Transformation()
 
 
+def compose(*parts: Transformation) -> Transformation:
+    """`a * b * c` as the scene parser evaluates it: starts from the identity and multiplies left to
+    right (reference include/scenefiles.hpp:731-785), which also fixes the signs of zeros."""
+    result = Transformation()
+    for p in parts:
+        result = result * p
+    return result
+
+
 def translation(vec) -> Transformation:
     v = np.asarray(vec, dtype=_f32)
     t = Transformation()
