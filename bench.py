@@ -121,10 +121,16 @@ def main():
         if world_size > 1:
             dist.barrier()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"scene uploaded: {scene.count('n_objects')} objects; frame {args.width}x{args.height} AA={args.aa}")
     # One stats pass (untimed): the ray count of a frame is deterministic (streams depend only on the sample index)
     step(want_stats=True)
     rays_local = int(tracer.last_stats.rays)
     samples_local = int(tracer.last_stats.samples)
+    log(f"stats pass: {rays_local} rays, {samples_local} samples, kernel {tracer.last_stats.kernel_ms:.1f} ms")
     for _ in range(max(args.warmup - 1, 0)):
         step()
     torch.cuda.synchronize()
@@ -138,6 +144,9 @@ def main():
         tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
         ev[k][1].record()
         gather_rows(local, args.height, full, padded=padded, parts=parts)
+        if args.steps > 1:
+            torch.cuda.current_stream().synchronize()
+            log(f"step {k + 1}/{args.steps} done")
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -177,6 +186,7 @@ def main():
                          "kernel_ms": kernel_ms},
         }
         if world_size == 1 and not args.no_cpu_baseline:
+            log("timing the CPU baseline on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(scene, text, args)
         if args.save_pfm:
             img = full.cpu().numpy()

@@ -60,6 +60,9 @@ enum { RT_MODE_ONOFF = 0, RT_MODE_FLAT = 1, RT_MODE_POINTLIGHT = 2, RT_MODE_PATH
 /* How path mode consumes random numbers (see rt_render_cfg::rng_mode) */
 enum { RT_RNG_PER_SAMPLE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
 
+/* rt_render_cfg::flags */
+#define RT_FLAG_EXACT_ARITHMETIC 1u
+
 /* Limits of the device CSG evaluator (fixed-capacity, no heap). */
 #define RT_MAX_CSG_DEPTH 8    /* nesting depth of CSG nodes below one top-level object */
 #define RT_MAX_CSG_LEAVES 32  /* Sphere/Plane leaves below one top-level CSG object    */
@@ -168,6 +171,12 @@ typedef struct rt_render_cfg {
    * Rank r of R with 16-row cyclic bands: band_rows = 16, band_stride = 16*R, band_offset = 16*r.
    */
   int32_t band_rows, band_stride, band_offset, n_local_rows;
+  /*
+   * RT_FLAG_EXACT_ARITHMETIC: path mode evaluates the closest-hit scan with the reference's unfused
+   * fp32 operation order (as the deterministic modes always do) instead of the fused-multiply-add
+   * form.  Slower; for parity work.  The deterministic modes ignore the flag (always exact).
+   */
+  uint32_t flags;
 } rt_render_cfg;
 
 typedef struct rt_stats {

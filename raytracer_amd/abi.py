@@ -18,6 +18,7 @@ RT_PIGMENT_UNIFORM, RT_PIGMENT_CHECKERED, RT_PIGMENT_IMAGE = 0, 1, 2
 RT_CAMERA_ORTHOGONAL, RT_CAMERA_PERSPECTIVE = 0, 1
 RT_MODE_ONOFF, RT_MODE_FLAT, RT_MODE_POINTLIGHT, RT_MODE_PATH = 0, 1, 2, 3
 RT_RNG_PER_SAMPLE_STREAMS, RT_RNG_SERIAL_REFERENCE = 0, 1
+RT_FLAG_EXACT_ARITHMETIC = 1
 RT_MAX_CSG_DEPTH = 8
 RT_MAX_CSG_LEAVES = 32
 
@@ -58,7 +59,7 @@ class rt_render_cfg(C.Structure):
         ("seq_number", C.c_uint64), ("background", C.c_float * 3), ("ambient", C.c_float * 3),
         ("max_mirror_bounces", C.c_int32), ("rng_mode", C.c_uint32),
         ("band_rows", C.c_int32), ("band_stride", C.c_int32), ("band_offset", C.c_int32),
-        ("n_local_rows", C.c_int32),
+        ("n_local_rows", C.c_int32), ("flags", C.c_uint32),
     ]
 
 

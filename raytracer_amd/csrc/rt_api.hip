@@ -404,7 +404,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   unsigned grid;
   if (cfg->mode == RT_MODE_PATH) {
     int per_cu = 0;
-    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path, BLOCK, 0));
+    const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
+    if (exact)
+      RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path<false>, BLOCK, 0));
+    else
+      RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path<true>, BLOCK, 0));
     per_cu = std::max(per_cu, 1);
     const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
@@ -425,7 +429,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   case RT_MODE_ONOFF: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_ONOFF>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
   case RT_MODE_FLAT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_FLAT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
   case RT_MODE_POINTLIGHT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_POINTLIGHT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
-  default: hipLaunchKernelGGL(rtd::k_render_path, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
+  default:
+    if (cfg->flags & RT_FLAG_EXACT_ARITHMETIC)
+      hipLaunchKernelGGL(rtd::k_render_path<false>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p);
+    else
+      hipLaunchKernelGGL(rtd::k_render_path<true>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p);
+    break;
   }
   RT_HIP(hipGetLastError());
   if (spp2 > 1) {

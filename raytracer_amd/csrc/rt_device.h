@@ -334,42 +334,119 @@ RT_DEV bool csg_ray_intersection(const Scene &s, const CsgTop &top, const Ray &r
 // World — include/shapes.hpp:520-604
 // ---------------------------------------------------------------------------------------------
 
-// Wave-uniform read of a scan record field: the address is the same in every lane, so the load
-// can be scalar (s_load) and the operand lives in SGPRs.
-typedef const __attribute__((address_space(4))) float *ConstF;
-RT_DEV ConstF scan_inv(const ScanRec *recs, int i) { return (ConstF)(uintptr_t)(recs[i].inv); }
+// Wave-uniform read of a scan record: the address is the same in every lane, so the 64-byte
+// record is fetched by ONE scalar load (s_load_dwordx16 from the constant address space) and its
+// fields are SGPR operands of the lanes' VALU instructions.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) f32x16 *ConstRecV;
+struct RecRegs {
+  f32x16 v; // inv[0..11], object, shape, pad, pad
+  RT_DEV float operator[](int k) const { return v[k]; }
+  RT_DEV int object() const { return __float_as_int(v[12]); }
+  RT_DEV int shape() const { return __float_as_int(v[13]); }
+};
+RT_DEV RecRegs load_rec(const ScanRec *recs, int i) {
+  RecRegs r;
+  r.v = ((ConstRecV)(uintptr_t)recs)[i];
+  return r;
+}
 
-// Front hit t of a top-level sphere (Sphere::ray_intersection, shapes.hpp:206-221)
-template <typename P> RT_DEV bool sphere_front_t(P inv, const Ray &ray_world, float &t) {
+// Front hit t of a top-level sphere / plane (Sphere::ray_intersection, shapes.hpp:206-221;
+// Plane::ray_intersection, shapes.hpp:322-341), reference operation order, nothing fused.
+template <typename P> RT_DEV bool sphere_front_t(const P &inv, const Ray &ray_world, float &t) {
   Ray ray = ray_transform(ray_world, inv);
   float tb;
   return solve_ray_sphere(ray, t, tb) > 0;
 }
-template <typename P> RT_DEV bool plane_front_t(P inv, const Ray &ray_world, float &t) {
+template <typename P> RT_DEV bool plane_front_t(const P &inv, const Ray &ray_world, float &t) {
   Ray ray = ray_transform(ray_world, inv);
   return solve_ray_plane(ray, t);
 }
 
-// World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
-// (strict `<` in insertion order).  The full record is built for the winner only.
-RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
-  float best_t = INF_F;
-  int best_obj = 0x7fffffff, best_shape = -1;
-  for (int i = 0; i < s.n_spheres; ++i) {
+struct Best {
+  float t;
+  int object, shape;
+};
+
+// One sphere test of the closest-hit scan.
+//  FAST == false: the reference's arithmetic, operation for operation (deterministic modes).
+//  FAST == true : the same quantities with fused multiply-adds and one reciprocal (path mode, whose
+//                 parity bar is statistical): 33 VALU instructions up to the discriminant test
+//                 instead of 52 flops unfused.  a > 0 and sqrt > 0 give t1 < t2 without the swap.
+template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &ray, Best &best) {
+  if (FAST) {
+    const RecRegs &m = r;
+    const float dx = fmaf(m[0], ray.d.x, fmaf(m[1], ray.d.y, m[2] * ray.d.z));
+    const float dy = fmaf(m[3], ray.d.x, fmaf(m[4], ray.d.y, m[5] * ray.d.z));
+    const float dz = fmaf(m[6], ray.d.x, fmaf(m[7], ray.d.y, m[8] * ray.d.z));
+    const float ox = fmaf(m[0], ray.o.x, fmaf(m[1], ray.o.y, fmaf(m[2], ray.o.z, m[9])));
+    const float oy = fmaf(m[3], ray.o.x, fmaf(m[4], ray.o.y, fmaf(m[5], ray.o.z, m[10])));
+    const float oz = fmaf(m[6], ray.o.x, fmaf(m[7], ray.o.y, fmaf(m[8], ray.o.z, m[11])));
+    const float a = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float b = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
+    const float c = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
+    const float disc = fmaf(b, b, -(a * c));
+    if (disc > 0.f) {
+      const float sq = sqrtf(disc);
+      const float inv_a = 1.f / a;
+      const float t1 = (-b - sq) * inv_a;
+      const float t2 = (-b + sq) * inv_a;
+      float t = t1;
+      bool ok = true;
+      if (t1 < ray.tmin) {
+        t = t2;
+        ok = t2 > ray.tmin && t2 < ray.tmax;
+      }
+      if (ok && t < best.t) {
+        best.t = t;
+        best.object = r.object();
+        best.shape = r.shape();
+      }
+    }
+  } else {
     float t;
-    if (sphere_front_t(scan_inv(s.spheres, i), ray, t) && t < best_t) {
-      best_t = t;
-      best_obj = s.spheres[i].object;
-      best_shape = s.spheres[i].shape;
+    if (sphere_front_t(r, ray, t) && t < best.t) {
+      best.t = t;
+      best.object = r.object();
+      best.shape = r.shape();
     }
   }
+}
+
+// The scan over the top-level spheres, in World::objects order (strict `<`: the lowest index wins
+// ties).  Records ping-pong between two SGPR sets so that the scalar load of the next record is in
+// flight while the lanes test the current one.
+template <bool FAST> RT_DEV void scan_spheres(const Scene &s, const Ray &ray, Best &best) {
+  const int n = s.n_spheres;
+  if (n <= 0)
+    return;
+  RecRegs a = load_rec(s.spheres, 0);
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    const RecRegs b = load_rec(s.spheres, i + 1);
+    sphere_scan_test<FAST>(a, ray, best);
+    a = load_rec(s.spheres, min(i + 2, n - 1));
+    sphere_scan_test<FAST>(b, ray, best);
+  }
+  if (i < n)
+    sphere_scan_test<FAST>(a, ray, best);
+}
+
+// World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
+// (strict `<` in insertion order).  The full record is built for the winner only.
+template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
+  Best best;
+  best.t = INF_F;
+  best.object = 0x7fffffff;
+  best.shape = -1;
+  scan_spheres<FAST>(s, ray, best);
   for (int i = 0; i < s.n_planes; ++i) {
+    const RecRegs r = load_rec(s.planes, i);
     float t;
-    const int obj = s.planes[i].object;
-    if (plane_front_t(scan_inv(s.planes, i), ray, t) && (t < best_t || (t == best_t && obj < best_obj))) {
-      best_t = t;
-      best_obj = obj;
-      best_shape = s.planes[i].shape;
+    if (plane_front_t(r, ray, t) && (t < best.t || (t == best.t && r.object() < best.object))) {
+      best.t = t;
+      best.object = r.object();
+      best.shape = r.shape();
     }
   }
   Hit h;
@@ -381,21 +458,21 @@ RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
   for (int i = 0; i < s.n_csg_tops; ++i) {
     const CsgTop top = s.csg_tops[i];
     Hit c;
-    if (csg_ray_intersection(s, top, ray, c) && (c.t < best_t || (c.t == best_t && c.object < best_obj))) {
-      best_t = c.t;
-      best_obj = c.object;
+    if (csg_ray_intersection(s, top, ray, c) && (c.t < best.t || (c.t == best.t && c.object < best.object))) {
+      best.t = c.t;
+      best.object = c.object;
       h = c;
       csg_won = true;
     }
   }
-  if (best_shape < 0 && !csg_won)
+  if (best.shape < 0 && !csg_won)
     return h;
   if (!csg_won) {
-    Ray local = ray_transform(ray, s.shape_inv + 12 * best_shape);
-    h.object = best_obj;
-    h.shape = best_shape;
-    h.t = best_t;
-    make_hit(s, best_shape, local, best_t, h.point, h.normal, h.local);
+    Ray local = ray_transform(ray, s.shape_inv + 12 * best.shape);
+    h.object = best.object;
+    h.shape = best.shape;
+    h.t = best.t;
+    make_hit(s, best.shape, local, best.t, h.point, h.normal, h.local);
   }
   return h;
 }
@@ -404,12 +481,14 @@ RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
 RT_DEV bool world_any_hit(const Scene &s, const Ray &ray) {
   bool hit = false;
   for (int i = 0; i < s.n_spheres && !hit; ++i) {
+    const RecRegs r = load_rec(s.spheres, i);
     float t;
-    hit = sphere_front_t(scan_inv(s.spheres, i), ray, t);
+    hit = sphere_front_t(r, ray, t);
   }
   for (int i = 0; i < s.n_planes && !hit; ++i) {
+    const RecRegs r = load_rec(s.planes, i);
     float t;
-    hit = plane_front_t(scan_inv(s.planes, i), ray, t);
+    hit = plane_front_t(r, ray, t);
   }
   for (int i = 0; i < s.n_csg_tops && !hit; ++i) {
     Hit c;
@@ -429,9 +508,10 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
   if (dot3(in_dir, normal) > 0.f)
     return false;
   for (int i = 0; i < s.n_spheres; ++i) {
+    const RecRegs r = load_rec(s.spheres, i);
     float t;
-    if (sphere_front_t(scan_inv(s.spheres, i), in_ray, t) && t < 1.f) {
-      const int shape = s.spheres[i].shape;
+    if (sphere_front_t(r, in_ray, t) && t < 1.f) {
+      const int shape = r.shape();
       Ray local = ray_transform(in_ray, s.shape_inv + 12 * shape);
       V3 p = hom_point(s.shape_fwd + 12 * shape, add3(local.o, lscale3(t, local.d)));
       if (!point_is_close(p, surface))
@@ -439,9 +519,10 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
     }
   }
   for (int i = 0; i < s.n_planes; ++i) {
+    const RecRegs r = load_rec(s.planes, i);
     float t;
-    if (plane_front_t(scan_inv(s.planes, i), in_ray, t) && t < 1.f) {
-      const int shape = s.planes[i].shape;
+    if (plane_front_t(r, in_ray, t) && t < 1.f) {
+      const int shape = r.shape();
       Ray local = ray_transform(in_ray, s.shape_inv + 12 * shape);
       V3 p = hom_point(s.shape_fwd + 12 * shape, add3(local.o, lscale3(t, local.d)));
       if (!point_is_close(p, surface))

@@ -64,7 +64,7 @@ template <int MODE> RT_DEV V3 shade_simple(const Scene &s, const RenderParams &p
   }
   if (MODE == RT_MODE_FLAT) {
     ++rays;
-    Hit h = world_ray_intersection(s, ray);
+    Hit h = world_ray_intersection<false>(s, ray);
     if (h.object < 0)
       return background;
     const uint32_t m = s.shape_material[h.shape];
@@ -80,7 +80,7 @@ template <int MODE> RT_DEV V3 shade_simple(const Scene &s, const RenderParams &p
   int bounces = 0;
   for (;;) {
     ++rays;
-    h = world_ray_intersection(s, ray);
+    h = world_ray_intersection<false>(s, ray);
     if (h.object < 0)
       return background;
     m = s.shape_material[h.shape];
@@ -144,7 +144,7 @@ RT_DEV float *stack_word(const RenderParams &p, int level, int word, uint32_t la
   return p.stack + ((size_t)(level * STACK_WORDS + word) * p.n_lanes + lane);
 }
 
-__global__ void __launch_bounds__(256) k_render_path(Scene s, RenderParams p) {
+template <bool FAST> __global__ void __launch_bounds__(256) k_render_path(Scene s, RenderParams p) {
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   const V3 background = mk3(p.background[0], p.background[1], p.background[2]);
   const float inv_n_rays = 1.f / (float)p.n_rays;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_render_path(Scene s, RenderParams p) {
     if (active) {
       // -- one closest-hit query ------------------------------------------------------------------
       ++rays;
-      Hit h = world_ray_intersection(s, ray);
+      Hit h = world_ray_intersection<FAST>(s, ray);
       // -- PathTracer::operator() steps 2-4 for this node -------------------------------------------
       if (h.object < 0) {
         radiance = add3(radiance, mul3(throughput, background));
@@ -301,7 +301,7 @@ __global__ void k_trace_rays(Scene s, const rt_ray *rays, size_t n, rt_hit *hits
   r.d = ld3(rays[i].direction);
   r.tmin = rays[i].tmin;
   r.tmax = rays[i].tmax;
-  Hit h = world_ray_intersection(s, r);
+  Hit h = world_ray_intersection<false>(s, r);
   rt_hit out;
   out.object = h.object;
   out.shape = h.shape;

@@ -32,6 +32,7 @@ class RenderMode:
     background: tuple = (0.0, 0.0, 0.0)          # BLACK, raytracer.cpp:337,348,352
     ambient: tuple = (0.1, 0.1, 0.1)             # DARK_GREY, renderers.hpp:103
     max_mirror_bounces: int = 64                 # the reference has no cap (renderers.hpp:129-152)
+    exact: bool = False                          # path mode: unfused reference-order arithmetic in the scan
 
 
 @dataclass
@@ -144,6 +145,7 @@ class GpuImageTracer:
         cfg.rng_mode = abi.RT_RNG_PER_SAMPLE_STREAMS
         cfg.band_rows, cfg.band_stride, cfg.band_offset = rows.band_rows, rows.band_stride, rows.band_offset
         cfg.n_local_rows = rows.n_local_rows
+        cfg.flags = abi.RT_FLAG_EXACT_ARITHMETIC if mode.exact else 0
         return cfg
 
     def fire_all_rays(self, world: DeviceWorld, mode: RenderMode, rows: RowBands | None = None, out=None,

@@ -45,7 +45,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                           "pigment_tex_height", "texels", "light_radius"],
         "rt_camera": ["kind", "fwd", "asp_ratio", "has_asp_ratio", "distance"],
         "rt_render_cfg": ["width", "mode", "seq_number", "background", "ambient", "max_mirror_bounces", "rng_mode",
-                          "band_rows", "n_local_rows"],
+                          "band_rows", "n_local_rows", "flags"],
         "rt_stats": ["rays", "samples", "capped_samples", "kernel_ms"],
         "rt_hit": ["object", "shape", "t", "point", "normal", "uv"],
         "rt_ray": ["origin", "direction", "tmin", "tmax"],

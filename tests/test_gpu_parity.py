@@ -147,15 +147,18 @@ def test_aa_jitter_exact():
     ("csg_example", 32, 24, 2, 3, 2, 4, 7),
     ("demo_path", 24, 16, 1, 1, 2, 40, 11),   # n_rays == 1: tail-call frames, deep recursion
 ])
-def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, roulette, max_depth, seq):
-    """Same per-sample PCG streams on both sides -> the same paths; only ulp-level libm differences remain."""
+@pytest.mark.parametrize("exact", [True, False])
+def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, roulette, max_depth, seq, exact):
+    """Same per-sample PCG streams on both sides -> the same paths; only ulp-level libm differences remain
+    (exact=True: unfused scan arithmetic; exact=False: the default fused-multiply-add scan of path mode)."""
     img, stats = gpu_render(worlds, scenes, scene, "path", w, h, aa, n_rays=n_rays, roulette=roulette, max_depth=max_depth,
-                            seq_number=seq)
+                            seq_number=seq, exact=exact)
     cfg = O.make_cfg(w, h, "path", spp_edge=aa, n_rays=n_rays, roulette=roulette, max_depth=max_depth, seq_number=seq,
                      rng_mode=abi.RT_RNG_PER_SAMPLE_STREAMS)
     want, ostats = O.render(scenes[scene], cfg)
     diff = np.abs(img - want).max(axis=-1)
     outliers = diff > 1e-4
+    print(f"exact={exact}: {int(outliers.sum())} of {outliers.size} pixels differ by > 1e-4, {int((diff == 0).sum())} identical")
     assert outliers.mean() <= 0.02, f"{outliers.sum()} of {outliers.size} pixels differ (max {diff.max()})"
     # a path that diverges near the root takes its whole subtree (up to ~10^max_depth rays) with it
     assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
