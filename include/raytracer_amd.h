@@ -62,6 +62,7 @@ enum { RT_RNG_PER_SAMPLE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
 
 /* rt_render_cfg::flags */
 #define RT_FLAG_EXACT_ARITHMETIC 1u
+#define RT_FLAG_OBJECT_SPACE_SPHERES 2u
 
 /* Limits of the device CSG evaluator (fixed-capacity, no heap). */
 #define RT_MAX_CSG_DEPTH 8    /* nesting depth of CSG nodes below one top-level object */
@@ -175,6 +176,9 @@ typedef struct rt_render_cfg {
    * RT_FLAG_EXACT_ARITHMETIC: path mode evaluates the closest-hit scan with the reference's unfused
    * fp32 operation order (as the deterministic modes always do) instead of the fused-multiply-add
    * form.  Slower; for parity work.  The deterministic modes ignore the flag (always exact).
+   * RT_FLAG_OBJECT_SPACE_SPHERES: path mode on large worlds tests every sphere in its own frame
+   * (inverse matrix, as the reference does) even when all spheres are translation * uniform scaling
+   * and could be tested in world space from (centre, r^2).
    */
   uint32_t flags;
 } rt_render_cfg;

@@ -272,6 +272,19 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       cb.tops.back().leaf_end = static_cast<int32_t>(cb.leaves.size());
     }
   }
+  // translation * uniform scaling spheres can be tested in world space from (centre, r^2)
+  std::vector<float> sphere_iso(spheres.size() * 4);
+  bool all_iso = !spheres.empty();
+  for (size_t i = 0; i < spheres.size(); ++i) {
+    const float *inv = spheres[i].inv;
+    const float *fwd = d->shape_fwd + 12 * static_cast<size_t>(spheres[i].shape);
+    const bool iso = inv[0] > 0.f && inv[4] == inv[0] && inv[8] == inv[0] && inv[1] == 0.f && inv[2] == 0.f && inv[3] == 0.f &&
+                     inv[5] == 0.f && inv[6] == 0.f && inv[7] == 0.f && fwd[0] > 0.f && fwd[4] == fwd[0] && fwd[8] == fwd[0] &&
+                     fwd[1] == 0.f && fwd[2] == 0.f && fwd[3] == 0.f && fwd[5] == 0.f && fwd[6] == 0.f && fwd[7] == 0.f;
+    all_iso = all_iso && iso;
+    sphere_iso[4 * i + 0] = fwd[9], sphere_iso[4 * i + 1] = fwd[10], sphere_iso[4 * i + 2] = fwd[11];
+    sphere_iso[4 * i + 3] = fwd[0] * fwd[0];
+  }
   std::vector<uint8_t> needs_uv(d->n_materials);
   for (uint32_t m = 0; m < d->n_materials; ++m)
     needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
@@ -303,6 +316,8 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   if ((st = (expr)) != RT_OK)                                                                              \
   return bail(st)
   UP(upload(sc, spheres, &S.spheres));
+  UP(upload(sc, sphere_iso, &S.sphere_iso));
+  S.spheres_all_iso = all_iso ? 1 : 0;
   UP(upload(sc, planes, &S.planes));
   UP(upload(sc, cb.tops, &S.csg_tops));
   S.n_spheres = static_cast<int32_t>(spheres.size());
@@ -401,18 +416,34 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   }
 
   constexpr int BLOCK = 256;
-  unsigned grid;
+  unsigned grid, block = BLOCK;
+  const void *path_kernel = nullptr;
   if (cfg->mode == RT_MODE_PATH) {
-    int per_cu = 0;
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
-    if (exact)
-      RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path<false>, BLOCK, 0));
-    else
-      RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtd::k_render_path<true>, BLOCK, 0));
+    path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
+    // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
+    const int rows = sc->dev.n_spheres / (64 * rtd::WIDE_WAVES);
+    if (!exact && rows >= 1) {
+      block = rtd::WIDE_THREADS;
+      if (sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES)) {
+        if (rows <= 1) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 1>);
+        else if (rows <= 2) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 2>);
+        else if (rows <= 4) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 4>);
+        else if (rows <= 8) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 8>);
+        else path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 16>);
+      } else {
+        if (rows <= 1) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 1>);
+        else if (rows <= 2) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 2>);
+        else if (rows <= 4) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 4>);
+        else path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 8>);
+      }
+    }
+    int per_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), 0));
     per_cu = std::max(per_cu, 1);
-    const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
+    const uint64_t want = (p.n_samples + block - 1) / block;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
-    p.n_lanes = grid * BLOCK;
+    p.n_lanes = grid * block;
     p.stack_levels = cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1);
     if (rt_status st = ensure(sc->stack, static_cast<size_t>(p.stack_levels) * rtd::STACK_WORDS * p.n_lanes * sizeof(float)))
       return st;
@@ -429,12 +460,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   case RT_MODE_ONOFF: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_ONOFF>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
   case RT_MODE_FLAT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_FLAT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
   case RT_MODE_POINTLIGHT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_POINTLIGHT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
-  default:
-    if (cfg->flags & RT_FLAG_EXACT_ARITHMETIC)
-      hipLaunchKernelGGL(rtd::k_render_path<false>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p);
-    else
-      hipLaunchKernelGGL(rtd::k_render_path<true>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p);
+  default: {
+    void *args[] = {&sc->dev, &p};
+    RT_HIP(hipLaunchKernel(path_kernel, dim3(grid), dim3(block), args, 0, stream));
     break;
+  }
   }
   RT_HIP(hipGetLastError());
   if (spp2 > 1) {

@@ -416,8 +416,7 @@ template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &r
 // The scan over the top-level spheres, in World::objects order (strict `<`: the lowest index wins
 // ties).  Records ping-pong between two SGPR sets so that the scalar load of the next record is in
 // flight while the lanes test the current one.
-template <bool FAST> RT_DEV void scan_spheres(const Scene &s, const Ray &ray, Best &best) {
-  const int n = s.n_spheres;
+template <bool FAST> RT_DEV void scan_spheres(const Scene &s, int n, const Ray &ray, Best &best) {
   if (n <= 0)
     return;
   RecRegs a = load_rec(s.spheres, 0);
@@ -432,14 +431,9 @@ template <bool FAST> RT_DEV void scan_spheres(const Scene &s, const Ray &ray, Be
     sphere_scan_test<FAST>(a, ray, best);
 }
 
-// World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
-// (strict `<` in insertion order).  The full record is built for the winner only.
-template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
-  Best best;
-  best.t = INF_F;
-  best.object = 0x7fffffff;
-  best.shape = -1;
-  scan_spheres<FAST>(s, ray, best);
+// Second half of World::ray_intersection (shapes.hpp:547-561) once the spheres have been scanned:
+// planes and CSG objects, ties to the lowest object index, full record for the winner only.
+RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
   for (int i = 0; i < s.n_planes; ++i) {
     const RecRegs r = load_rec(s.planes, i);
     float t;
@@ -475,6 +469,17 @@ template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray
     make_hit(s, best.shape, local, best.t, h.point, h.normal, h.local);
   }
   return h;
+}
+
+// World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
+// (strict `<` in insertion order).
+template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
+  Best best;
+  best.t = INF_F;
+  best.object = 0x7fffffff;
+  best.shape = -1;
+  scan_spheres<FAST>(s, s.n_spheres, ray, best);
+  return world_finish_hit(s, ray, best);
 }
 
 // World::on_off_ray_intersection — shapes.hpp:567-578 (only the boolean is used, renderers.hpp:62-69)

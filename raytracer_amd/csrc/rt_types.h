@@ -49,6 +49,8 @@ struct CsgProgEntry {  // RPN program "is point inside this subtree?"
 struct Scene {
   // scan lists
   const ScanRec *spheres; int32_t n_spheres;
+  const float *sphere_iso;        // [n_spheres][4] world centre + r^2, valid iff spheres_all_iso
+  int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   const ScanRec *planes;  int32_t n_planes;
   const CsgTop *csg_tops; int32_t n_csg_tops;
   int32_t n_objects;

@@ -223,3 +223,66 @@ def test_error_behaviour(worlds, scenes):
     broken.shape_material[0] = 99
     with pytest.raises(RtError):
         DeviceWorld(broken)
+
+
+# ---- the wide path kernel (worlds with >= 512 top-level spheres: spheres in registers, rays through LDS) ----
+
+def _ellipsoid_world(n, seed=5):
+    """n random ellipsoids (rotated, non-uniformly scaled: the general affine register form) + floor + sky."""
+    from raytracer_amd.scene import SceneBuilder, compose, rotation_x, rotation_z, scaling, translation
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    floor = b.material("diffuse", b.pigment_checkered((0.3, 0.5, 0.1), (0.1, 0.2, 0.5), 4))
+    sky = b.material("diffuse", b.pigment_uniform((0, 0, 0)), b.pigment_uniform((0.2, 0.3, 1.0)))
+    mats = [b.material("diffuse", b.pigment_uniform(tuple(rng.uniform(0.2, 0.9, 3)))) for _ in range(6)]
+    mats.append(b.material("specular", b.pigment_uniform((0.7, 0.7, 0.7))))
+    b.plane(compose(translation([0, 0, -1])), floor)
+    b.sphere(compose(scaling([40, 40, 40])), sky)
+    for _ in range(n):
+        c = rng.uniform([-1, -3, -0.8], [5, 3, 1.5])
+        sc = rng.uniform(0.08, 0.3, 3)
+        t = compose(translation(c), rotation_z(rng.uniform(0, 3)), rotation_x(rng.uniform(0, 3)), scaling(sc))
+        b.sphere(t, mats[int(rng.integers(len(mats)))])
+    b.set_camera("perspective", compose(translation([-3, 0, 0.3])), None, 1.0)
+    return b.build()
+
+
+@pytest.mark.parametrize("kind,n", [("iso", 600), ("iso", 1100), ("general", 700)])
+def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
+    """Same per-sample streams on the wide kernel and on the CPU oracle -> the same paths (FMA / world-space
+    sphere arithmetic moves t by ulps, so a few paths diverge at discontinuities)."""
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(n)[0] if kind == "iso" else _ellipsoid_world(n)
+    world = DeviceWorld(scene)
+    w, h, aa, kw = 40, 24, 1, dict(n_rays=3, roulette=2, max_depth=3, seq_number=9)
+    tr = GpuImageTracer(w, h, scene.camera, aa)
+    img = tr.fire_all_rays(world, RenderMode("path", **kw))
+    stats = tr.last_stats
+    exact = tr.fire_all_rays(world, RenderMode("path", exact=True, **kw))  # the per-lane kernel, unfused arithmetic
+    objsp = tr.fire_all_rays(world, RenderMode("path", object_space_spheres=True, **kw))  # wide kernel, object-space form
+    world.close()
+    want, ostats = O.render(scene, O.make_cfg(w, h, "path", spp_edge=aa, rng_mode=abi.RT_RNG_PER_SAMPLE_STREAMS, **kw))
+    for name, got in (("wide", img), ("wide-object-space", objsp), ("exact", exact)):
+        diff = np.abs(got - want).max(axis=-1)
+        outliers = diff > 1e-4
+        print(f"{kind} n={n} {name}: {int(outliers.sum())} of {outliers.size} pixels differ by > 1e-4 (max {diff.max():.3g})")
+        assert outliers.mean() <= 0.10
+        assert abs(float(got.mean()) - float(want.mean())) <= 0.01 * float(want.mean())
+    assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
+
+
+def test_path_wide_kernel_row_bands_and_determinism():
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(512)[0]
+    world = DeviceWorld(scene)
+    kw = dict(n_rays=3, roulette=2, max_depth=3)
+    tr = GpuImageTracer(48, 40, scene.camera, 2)
+    whole = tr.fire_all_rays(world, RenderMode("path", **kw))
+    again = tr.fire_all_rays(world, RenderMode("path", **kw))
+    assert np.array_equal(whole, again)  # sample -> lane assignment is dynamic, the image is not
+    out = np.zeros_like(whole)
+    for rank in range(3):
+        rows = RowBands.cyclic(40, rank, 3, band_rows=16)
+        out[rows.image_rows()] = tr.fire_all_rays(world, RenderMode("path", **kw), rows)
+    world.close()
+    assert np.array_equal(out, whole)
