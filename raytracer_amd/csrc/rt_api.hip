@@ -217,6 +217,14 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 
 } // namespace
 
+// Selectors of the instantiated k_render_path_wide<ISO, K, W> shapes (rt_wide_iso.hip / rt_wide_gen.hip;
+// separate translation units so that the ~30 kernels compile in parallel).
+const void *rt_wide_kernel_iso(int k, int waves);
+const void *rt_wide_kernel_gen(int k, int waves);
+
+namespace {
+} // namespace
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
@@ -354,7 +362,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.n_lights = static_cast<int32_t>(d->n_lights);
 #undef UP
   void *cnt = nullptr;
-  if (hipMalloc(&cnt, 4 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc(&cnt, 16 * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed"));
   sc->counters = static_cast<unsigned long long *>(cnt);
   if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
@@ -422,21 +430,18 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
-    const int rows = sc->dev.n_spheres / (64 * rtd::WIDE_WAVES);
-    if (!exact && rows >= 1) {
-      block = rtd::WIDE_THREADS;
-      if (sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES)) {
-        if (rows <= 1) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 1>);
-        else if (rows <= 2) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 2>);
-        else if (rows <= 4) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 4>);
-        else if (rows <= 8) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 8>);
-        else path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<true, 16>);
-      } else {
-        if (rows <= 1) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 1>);
-        else if (rows <= 2) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 2>);
-        else if (rows <= 4) path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 4>);
-        else path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wide<false, 8>);
-      }
+    const int rows = sc->dev.n_spheres / 64;
+    if (!exact && rows >= 4) {
+      const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
+      // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
+      // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.
+      const int kmax = iso ? 8 : 4;
+      int waves = 1;
+      while (waves < 8 && rows > waves * kmax)
+        waves *= 2;
+      const int k = std::min((rows + waves - 1) / waves, kmax);
+      block = 64u * static_cast<unsigned>(waves);
+      path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
     }
     int per_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), 0));
@@ -453,7 +458,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 32));
   }
 
-  RT_HIP(hipMemsetAsync(sc->counters, 0, 4 * sizeof(unsigned long long), stream));
+  RT_HIP(hipMemsetAsync(sc->counters, 0, 16 * sizeof(unsigned long long), stream));
   if (stats)
     RT_HIP(hipEventRecord(sc->ev0, stream));
   switch (cfg->mode) {
@@ -475,8 +480,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   if (stats) {
     RT_HIP(hipEventRecord(sc->ev1, stream));
     RT_HIP(hipEventSynchronize(sc->ev1));
-    unsigned long long c[4];
+    unsigned long long c[16];
     RT_HIP(hipMemcpy(c, sc->counters, sizeof c, hipMemcpyDeviceToHost));
+#ifdef RT_PROFILE_PHASES
+    if (c[7])
+      std::fprintf(stderr, "[rt phases] blocks*iters=%llu rays/iter=%.1f cycles/iter: queue=%.0f scan=%.0f shade=%.0f (100 MHz ticks x?)\n", c[7],
+                   double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]));
+#endif
     float ms = 0.f;
     RT_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
     stats->rays = c[1];

@@ -1,0 +1,263 @@
+// rt_wide.h — the path kernel for large worlds: spheres in registers, rays through an LDS queue.
+#pragma once
+#include "rt_path.h"
+
+namespace rtd {
+
+// ---------------------------------------------------------------------------------------------
+// Path kernel for large worlds ("wide"): the closest-hit scan is transposed.
+//
+//   * The top-level spheres live in REGISTERS, spread over the lanes of the workgroup: lane l of
+//     wave w holds K spheres per pass (64 * WAVES * K spheres per pass; more passes for bigger worlds).
+//     Nothing is streamed per test: the scalar cache cannot feed 64-byte records to every wave at the
+//     rate the VALU consumes them (measured: the record stream saturates near 1.4 TB/s chip-wide).
+//   * The rays of the workgroup's samples are compacted into an LDS queue (ballot + prefix count);
+//     every wave reads each queued ray as an LDS broadcast and tests it against its own spheres.
+//     A lane that finds a hit merges {t, object index} into the ray's 64-bit LDS key with one
+//     ds_min_u64: t > 0, so the float bits order like the numbers, and equal t falls to the lowest
+//     object index exactly as World::ray_intersection's strict `<` does.
+//   * Then every lane is a ray again: it completes the query (planes, CSG, hit record), shades the
+//     node and produces the next ray of its sample.
+//
+//   ISO: all spheres are translation * uniform scaling, tested in world space from (centre, r^2):
+//        oc = O - C; b = oc.D; c = oc.oc - r^2; disc = b^2 - (D.D) c      (12 VALU per test)
+//   otherwise the general affine form of sphere_scan_test<true> (inverse matrix, 28 VALU per test).
+// ---------------------------------------------------------------------------------------------
+// Workgroup = W waves; lane l of wave w holds K rows of 64 spheres.  One ray costs W * (12 K + c) wave
+// instructions (c ~ 25: LDS ray read, loop, max, branch), so W is kept as small as the register budget
+// allows: W * K >= number of 64-sphere rows, K <= 8 (ISO) / 4 (general) so that the kernel fits 128 VGPRs.
+
+struct alignas(16) WideRay { // LDS image of one queued ray: 3 x 16 bytes
+  float ox, oy, oz, tmin;
+  float dx, dy, dz, tmax;
+  float a, inv_a, pad0, pad1; // D.D and its reciprocal
+};
+
+template <bool ISO, int K> struct WideSlots;
+template <int K> struct WideSlots<true, K> {
+  float cx[K], cy[K], cz[K], r2[K];
+  RT_DEV void load(const Scene &s, int k, int sphere, bool valid) {
+    if (valid) {
+      const float4 v = reinterpret_cast<const float4 *>(s.sphere_iso)[sphere];
+      cx[k] = v.x, cy[k] = v.y, cz[k] = v.z, r2[k] = v.w;
+    } else { // empty slot: c = |oc|^2 + 1 makes disc <= -a < 0 (Cauchy-Schwarz), never a hit
+      cx[k] = cy[k] = cz[k] = 0.f;
+      r2[k] = -1.f;
+    }
+  }
+  RT_DEV float disc(int k, const WideRay &r, float &b) const {
+    const float ocx = r.ox - cx[k], ocy = r.oy - cy[k], ocz = r.oz - cz[k];
+    b = fmaf(ocx, r.dx, fmaf(ocy, r.dy, ocz * r.dz));
+    const float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2[k])));
+    return fmaf(b, b, -(r.a * c));
+  }
+  RT_DEV float a_of(int, const WideRay &r, float &inv_a) const {
+    inv_a = r.inv_a;
+    return r.a;
+  }
+};
+template <int K> struct WideSlots<false, K> {
+  float m[K][12];
+  float a_[K];
+  RT_DEV void load(const Scene &s, int k, int sphere, bool valid) {
+    if (valid) {
+      const float4 *v = reinterpret_cast<const float4 *>(s.spheres[sphere].inv);
+      const float4 v0 = v[0], v1 = v[1], v2 = v[2];
+      m[k][0] = v0.x, m[k][1] = v0.y, m[k][2] = v0.z, m[k][3] = v0.w;
+      m[k][4] = v1.x, m[k][5] = v1.y, m[k][6] = v1.z, m[k][7] = v1.w;
+      m[k][8] = v2.x, m[k][9] = v2.y, m[k][10] = v2.z, m[k][11] = v2.w;
+    } else { // empty slot: zero matrix, origin mapped to (2,0,0): a = b = 0, c = 3, disc = 0
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+        m[k][j] = 0.f;
+      m[k][9] = 2.f;
+    }
+  }
+  RT_DEV float disc(int k, const WideRay &r, float &b) {
+    const float *q = m[k];
+    const float dx = fmaf(q[0], r.dx, fmaf(q[1], r.dy, q[2] * r.dz));
+    const float dy = fmaf(q[3], r.dx, fmaf(q[4], r.dy, q[5] * r.dz));
+    const float dz = fmaf(q[6], r.dx, fmaf(q[7], r.dy, q[8] * r.dz));
+    const float ox = fmaf(q[0], r.ox, fmaf(q[1], r.oy, fmaf(q[2], r.oz, q[9])));
+    const float oy = fmaf(q[3], r.ox, fmaf(q[4], r.oy, fmaf(q[5], r.oz, q[10])));
+    const float oz = fmaf(q[6], r.ox, fmaf(q[7], r.oy, fmaf(q[8], r.oz, q[11])));
+    const float a = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    b = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
+    const float c = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
+    a_[k] = a;
+    return fmaf(b, b, -(a * c));
+  }
+  RT_DEV float a_of(int k, const WideRay &, float &inv_a) const {
+    inv_a = 1.f / a_[k];
+    return a_[k];
+  }
+};
+
+// Register budget: ISO rows cost 4 VGPRs, general rows 13.  Where the rows leave room, ask for 4 waves per
+// SIMD (<= 128 VGPRs), so that several workgroups share a CU and one's shading overlaps another's scan.
+template <bool ISO, int K, int W>
+__global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderParams p) {
+  constexpr int WIDE_WAVES = W;
+  constexpr int WIDE_THREADS = 64 * W;
+  __shared__ WideRay q_ray[WIDE_THREADS];
+  __shared__ unsigned long long q_key[WIDE_THREADS];
+  __shared__ int q_count;
+
+  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Spheres [wide_first, n_spheres) are held in registers as n_rows full rows of 64; the first
+  // wide_first (< 64) spheres of the list are scanned per lane with the other objects.  Row r of a
+  // pass belongs to wave r % W, register row r / W; rows past n_rows are never-hit dummies.
+  const int wide_first = s.n_spheres % 64;
+  const int n_rows = s.n_spheres / 64;
+  const int n_pass = (n_rows + K * WIDE_WAVES - 1) / (K * WIDE_WAVES);
+  PathLane L;
+  L.init();
+  WideSlots<ISO, K> slots;
+  if (n_pass == 1) { // the whole world fits: load the registers once
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      slots.load(s, k, wide_first + (k * WIDE_WAVES + wave) * 64 + lane, k * WIDE_WAVES + wave < n_rows);
+  }
+
+#ifdef RT_PROFILE_PHASES
+  unsigned long long t_queue = 0, t_scan = 0, t_shade = 0, n_iter = 0, n_rays_q = 0;
+#define RT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define RT_STAMP(var)
+#endif
+  for (;;) {
+    RT_STAMP(ts0);
+    // -- every lane is a sample: refill, then queue the live rays (compacted) ----------------------
+    if (threadIdx.x == 0)
+      q_count = 0;
+    L.refill(p);
+    __syncthreads();
+    int my_q = -1;
+    if (L.active) {
+      const unsigned long long live = __ballot(1);
+      const int rank = __popcll(live & ((1ull << lane) - 1ull));
+      int base = 0;
+      if (rank == 0)
+        base = atomicAdd(&q_count, __popcll(live));
+      base = __shfl(base, __ffsll((long long)live) - 1, 64);
+      my_q = base + rank;
+      WideRay r;
+      r.ox = L.ray.o.x, r.oy = L.ray.o.y, r.oz = L.ray.o.z, r.tmin = L.ray.tmin;
+      r.dx = L.ray.d.x, r.dy = L.ray.d.y, r.dz = L.ray.d.z, r.tmax = L.ray.tmax;
+      r.a = fmaf(r.dx, r.dx, fmaf(r.dy, r.dy, r.dz * r.dz));
+      r.inv_a = 1.f / r.a;
+      r.pad0 = r.pad1 = 0.f;
+      q_ray[my_q] = r;
+      q_key[my_q] = ~0ull;
+    }
+    __syncthreads();
+    const int n_q = q_count;
+    if (n_q == 0)
+      break; // no live sample in the workgroup and the call's queue is drained
+    RT_STAMP(ts1);
+
+    // -- every lane is K spheres: all waves test every queued ray ----------------------------------
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const int first = wide_first + pass * K * WIDE_WAVES * 64;
+      if (n_pass > 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, (pass * K + k) * WIDE_WAVES + wave < n_rows);
+      }
+      // One queued ray against this lane's K spheres.  The K discriminants are one straight-line block
+      // (no branch per sphere); the rare hit work sits behind a single wave-level branch.
+      auto test_ray = [&](const WideRay &r, int qi) {
+        float disc[K], b[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          disc[k] = slots.disc(k, r, b[k]);
+        float dmax = disc[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k)
+          dmax = fmaxf(dmax, disc[k]);
+        if (dmax > 0.f) {
+          float best_t = INF_F;
+          int best_k = -1;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            if (disc[k] > 0.f) {
+              float inv_a;
+              slots.a_of(k, r, inv_a);
+              const float sq = sqrtf(disc[k]);
+              const float t1 = (-b[k] - sq) * inv_a;
+              const float t2 = (-b[k] + sq) * inv_a;
+              float t = t1;
+              bool ok = true;
+              if (t1 < r.tmin) {
+                t = t2;
+                ok = t2 > r.tmin && t2 < r.tmax;
+              }
+              if (ok && t < best_t) { // ascending k = ascending object index within a lane
+                best_t = t;
+                best_k = k;
+              }
+            }
+          }
+          if (best_k >= 0) {
+            const int sphere = first + (best_k * WIDE_WAVES + wave) * 64 + lane;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)sphere;
+            atomicMin(&q_key[qi], key);
+          }
+        }
+      };
+      // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
+      // the lanes test the current one.
+      WideRay ra = q_ray[0];
+      int qi = 0;
+      for (; qi + 1 < n_q; qi += 2) {
+        const WideRay rb = q_ray[qi + 1];
+        test_ray(ra, qi);
+        ra = q_ray[min(qi + 2, n_q - 1)];
+        test_ray(rb, qi + 1);
+      }
+      if (qi < n_q)
+        test_ray(ra, qi);
+    }
+    __syncthreads();
+    RT_STAMP(ts2);
+
+    // -- every lane is a ray again: finish the query, shade, produce the next ray -------------------
+    if (L.active) {
+      const unsigned long long key = q_key[my_q];
+      Best best;
+      best.t = INF_F;
+      best.object = 0x7fffffff;
+      best.shape = -1;
+      scan_spheres<true>(s, wide_first, L.ray, best); // the few spheres that did not fill a register row
+      if (key != ~0ull) { // sphere list order == object order, so the key's tie-break is the reference's
+        const int sphere = (int)(unsigned)(key & 0xffffffffull);
+        const float t = __uint_as_float((unsigned)(key >> 32));
+        if (t < best.t) { // a register-held sphere has a higher index than any scanned one: strict <
+          best.t = t;
+          best.object = s.spheres[sphere].object;
+          best.shape = s.spheres[sphere].shape;
+        }
+      }
+      const Hit h = world_finish_hit(s, L.ray, best);
+      L.shade_and_advance(s, p, h, lane_global);
+    }
+    __syncthreads(); // q_count / q_ray are rewritten at the top
+#ifdef RT_PROFILE_PHASES
+    RT_STAMP(ts3);
+    t_queue += ts1 - ts0, t_scan += ts2 - ts1, t_shade += ts3 - ts2, n_iter += 1, n_rays_q += n_q;
+#endif
+  }
+#ifdef RT_PROFILE_PHASES
+  if (threadIdx.x == 0) {
+    atomicAdd(p.counters + 4, t_queue);
+    atomicAdd(p.counters + 5, t_scan);
+    atomicAdd(p.counters + 6, t_shade);
+    atomicAdd(p.counters + 7, n_iter);
+    atomicAdd(p.counters + 8, n_rays_q);
+  }
+#endif
+  wave_add_counter(p.counters + 1, L.rays);
+}
+
+} // namespace rtd
