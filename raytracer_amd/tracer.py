@@ -159,6 +159,9 @@ class GpuImageTracer:
                          `stream` = a raw hipStream_t (int) or None for torch's current stream.
         """
         cfg = self.make_cfg(mode, rows)
+        if cfg.n_local_rows == 0:  # a rank with no band of this frame (more ranks than bands)
+            self.last_stats = abi.rt_stats() if want_stats else None
+            return np.empty((0, self.width, 3), dtype=np.float32) if out is None else out
         cam = self.camera.to_abi()
         stats = abi.rt_stats()
         stats_p = C.byref(stats) if want_stats else None
