@@ -58,7 +58,7 @@ enum { RT_CAMERA_ORTHOGONAL = 0, RT_CAMERA_PERSPECTIVE = 1 };
 /* ModeCfg::Mode: src/raytracer.cpp:48 (--mode onoff|flat|pointlight|path) */
 enum { RT_MODE_ONOFF = 0, RT_MODE_FLAT = 1, RT_MODE_POINTLIGHT = 2, RT_MODE_PATH = 3 };
 /* How path mode consumes random numbers (see rt_render_cfg::rng_mode) */
-enum { RT_RNG_PER_SAMPLE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
+enum { RT_RNG_PER_NODE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
 
 /* rt_render_cfg::flags */
 #define RT_FLAG_EXACT_ARITHMETIC 1u
@@ -159,7 +159,7 @@ typedef struct rt_render_cfg {
    */
   int32_t max_mirror_bounces;
   /*
-   * RT_RNG_PER_SAMPLE_STREAMS: every pixel sample owns a PCG stream derived from
+   * RT_RNG_PER_NODE_STREAMS: every pixel sample owns a PCG stream derived from
    * (seq_number, global sample index); image independent of GPU count.  Statistical parity.
    * RT_RNG_SERIAL_REFERENCE is not available on the device (the reference consumes one stream
    * serially over the whole image); the value exists so that the CPU oracle can be asked for it.

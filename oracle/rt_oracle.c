@@ -164,8 +164,14 @@ static void pcg_advance(pcg_t *p, uint64_t n) {
   p->state = acc_mult * p->state + acc_plus;
 }
 
-/* splitmix64 finaliser: derives the per-sample path streams (RT_RNG_PER_SAMPLE_STREAMS).  The
- * device uses the same derivation (raytracer_amd/csrc/rt_device.h: sample_stream). */
+/* splitmix64 finaliser: derives the per-ray path streams of RT_RNG_PER_NODE_STREAMS (not in the
+ * reference, which consumes one serial PCG).  Every ray of a sample's recursion tree owns a stream:
+ *   root ray of global sample g : state = mix64(g ^ mix64(seq_number))
+ *   child k of a ray            : state = mix64(parent state after the parent's own draws + k * GOLDEN)
+ *   inc = (seq_number << 1) | 1 for all of them (what PCG(42, seq) has, include/random.hpp:41-47).
+ * A ray draws: [theta, phi of DiffusiveBRDF::scatter_ray if its parent is diffusive], then [the
+ * Russian-roulette number at its hit].  The device derives the same keys
+ * (raytracer_amd/csrc/rt_path.h: node_root_key / node_child_key). */
 static uint64_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -173,11 +179,8 @@ static uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-static void sample_stream(pcg_t *p, uint64_t seq_number, uint64_t global_sample) {
-  uint64_t init_state = mix64(global_sample ^ mix64(seq_number));
-  uint64_t init_seq = mix64(init_state);
-  pcg_init(p, init_state, init_seq);
-}
+static uint64_t node_root_key(uint64_t seq_number, uint64_t global_sample) { return mix64(global_sample ^ mix64(seq_number)); }
+static uint64_t node_child_key(uint64_t parent_state, uint32_t k) { return mix64(parent_state + (uint64_t)k * 0x9E3779B97F4A7C15ull); }
 
 /* PCG::random_phong — include/random.hpp:75-84 */
 static void pcg_random_phong(pcg_t *p, int n, float *theta, float *phi) {
@@ -586,6 +589,59 @@ static col3 shade_path(ctx_t *c, ray_t ray) {
   return c_add(cum, emitted);
 }
 
+/* PathTracer::operator() with RT_RNG_PER_NODE_STREAMS, in the form the device evaluates: the estimator
+ * L = Le + (rho/n) * sum L(child) is linear in the emitted radiance, so a sample's value is the sum over
+ * the nodes of its recursion tree of throughput(node) * Le(node), throughput(child) = throughput(parent)
+ * * (1/n_rays) * rho(parent).  Contributions are summed in 64-bit fixed point (2^-32), which makes the
+ * sum independent of the order of the nodes.  Children deeper than max_depth are BLACK without a
+ * query (renderers.hpp:210), so they are not created. */
+static int64_t to_fixed(float x) { return (int64_t)((double)x * 4294967296.0); }
+static float from_fixed(int64_t a) { return (float)((double)a * (1.0 / 4294967296.0)); }
+
+static void shade_path_nodes(ctx_t *c, ray_t ray, pcg_t pcg, col3 throughput, int64_t acc[3]) {
+  S *s = c->s;
+  const rt_render_cfg *cfg = c->cfg;
+  hit_t h;
+  col3 emitted, reflected = C_BLACK;
+  int scatter = 0;
+  uint32_t m = 0;
+  if (world_ray_intersection(s, ray, &h, &c->cnt) < 0) {
+    emitted = c_from(cfg->background);
+  } else {
+    m = s->shape_material[h.shape];
+    reflected = pigment_eval(s, s->material_brdf_pigment[m], h.u, h.v);
+    emitted = pigment_eval(s, s->material_emission_pigment[m], h.u, h.v);
+    float hit_lum = fmaxf(fmaxf(reflected.r, reflected.g), reflected.b);
+    scatter = hit_lum > 0.f;
+    if (ray.depth > cfg->roulette) {
+      float q = fmaxf(1.f - hit_lum, 0.05f);
+      if (pcg_random_float(&pcg) > q)
+        reflected = c_scale(reflected, 1.f / (1.f - q));
+      else
+        scatter = 0;
+    }
+    scatter = scatter && ray.depth < cfg->max_depth;
+  }
+  col3 contrib = c_mul(throughput, emitted);
+  acc[0] += to_fixed(contrib.r), acc[1] += to_fixed(contrib.g), acc[2] += to_fixed(contrib.b);
+  if (!scatter)
+    return;
+  col3 weight = c_mul(c_scale(throughput, 1.f / (float)cfg->n_rays), reflected);
+  for (int k = 0; k < cfg->n_rays; ++k) {
+    pcg_t child = {node_child_key(pcg.state, (uint32_t)k), pcg.inc};
+    ray_t new_ray = brdf_scatter_ray(s->material_brdf[m], &child, ray.d, h.point, h.normal, ray.depth + 1);
+    shade_path_nodes(c, new_ray, child, weight, acc);
+  }
+}
+
+static col3 shade_path_node_streams(ctx_t *c, ray_t ray, uint64_t global_sample) {
+  pcg_t pcg = {node_root_key(c->cfg->seq_number, global_sample), (c->cfg->seq_number << 1u) | 1u};
+  int64_t acc[3] = {0, 0, 0};
+  shade_path_nodes(c, ray, pcg, C_WHITE, acc);
+  col3 r = {from_fixed(acc[0]), from_fixed(acc[1]), from_fixed(acc[2])};
+  return r;
+}
+
 static col3 shade(ctx_t *c, ray_t ray) {
   switch (c->cfg->mode) {
   case RT_MODE_ONOFF: return shade_onoff(c, ray);
@@ -655,6 +711,7 @@ RTO_EXPORT int rto_render(const rt_scene_desc *s, const rt_camera *cam, const rt
   ctx_t ctx = {s, cfg, &path_pcg, {0, 0}};
   uint64_t samples = 0;
   const int serial = (cfg->rng_mode == RT_RNG_SERIAL_REFERENCE);
+  const int node_streams = (cfg->mode == RT_MODE_PATH && !serial);
   if (serial && !whole)
     return RT_ERR_INVALID_ARGUMENT; /* a serial stream cannot be sharded */
 
@@ -674,19 +731,16 @@ RTO_EXPORT int rto_render(const rt_scene_desc *s, const rt_camera *cam, const rt
             }
             float u_pixel = ((float)i + pcg_random_float(&aa_pcg)) / (float)spp;
             float v_pixel = ((float)j + pcg_random_float(&aa_pcg)) / (float)spp;
-            if (!serial) {
-              const uint64_t g = ((uint64_t)row * (uint64_t)W + (uint64_t)col) * (uint64_t)(spp * spp) + (uint64_t)(i * spp + j);
-              sample_stream(&path_pcg, cfg->seq_number, g);
-            }
-            cum = c_add(cum, shade(&ctx, camera_fire_ray(cam, W, H, col, row, u_pixel, v_pixel)));
+            const uint64_t g = ((uint64_t)row * (uint64_t)W + (uint64_t)col) * (uint64_t)(spp * spp) + (uint64_t)(i * spp + j);
+            const ray_t ray = camera_fire_ray(cam, W, H, col, row, u_pixel, v_pixel);
+            cum = c_add(cum, node_streams ? shade_path_node_streams(&ctx, ray, g) : shade(&ctx, ray));
             ++samples;
           }
         }
         cum = c_scale(cum, 1.f / (float)(spp * spp)); /* Color::operator/ — colors.hpp:145 */
       } else {
-        if (!serial)
-          sample_stream(&path_pcg, cfg->seq_number, (uint64_t)row * (uint64_t)W + (uint64_t)col);
-        cum = shade(&ctx, camera_fire_ray(cam, W, H, col, row, 0.5f, 0.5f));
+        const ray_t ray = camera_fire_ray(cam, W, H, col, row, 0.5f, 0.5f);
+        cum = node_streams ? shade_path_node_streams(&ctx, ray, (uint64_t)row * (uint64_t)W + (uint64_t)col) : shade(&ctx, ray);
         ++samples;
       }
       float *px = rgb_out + 3 * ((size_t)lr * (size_t)W + (size_t)col); /* HdrImage::set_pixel — colors.hpp:448-464 */
@@ -796,11 +850,11 @@ RTO_EXPORT void rto_pcg_advance(uint64_t st[2], uint64_t n) {
   pcg_advance(&p, n);
   st[0] = p.state;
 }
-RTO_EXPORT void rto_sample_stream(uint64_t st[2], uint64_t seq_number, uint64_t global_sample) {
-  pcg_t p;
-  sample_stream(&p, seq_number, global_sample);
-  st[0] = p.state, st[1] = p.inc;
+/* Stream of the root ray of a pixel sample (RT_RNG_PER_NODE_STREAMS) and of child k of a ray */
+RTO_EXPORT void rto_node_root_stream(uint64_t st[2], uint64_t seq_number, uint64_t global_sample) {
+  st[0] = node_root_key(seq_number, global_sample), st[1] = (seq_number << 1u) | 1u;
 }
+RTO_EXPORT void rto_node_child_stream(uint64_t st[2], uint32_t k) { st[0] = node_child_key(st[0], k); }
 
 /* The AA jitter pair of serial sample index k (include/cameras.hpp:232-233) via jump-ahead */
 RTO_EXPORT void rto_aa_jitter(const uint64_t *k, size_t n, float *u, float *v) {

@@ -17,7 +17,7 @@ RT_BRDF_DIFFUSE, RT_BRDF_SPECULAR = 0, 1
 RT_PIGMENT_UNIFORM, RT_PIGMENT_CHECKERED, RT_PIGMENT_IMAGE = 0, 1, 2
 RT_CAMERA_ORTHOGONAL, RT_CAMERA_PERSPECTIVE = 0, 1
 RT_MODE_ONOFF, RT_MODE_FLAT, RT_MODE_POINTLIGHT, RT_MODE_PATH = 0, 1, 2, 3
-RT_RNG_PER_SAMPLE_STREAMS, RT_RNG_SERIAL_REFERENCE = 0, 1
+RT_RNG_PER_NODE_STREAMS, RT_RNG_SERIAL_REFERENCE = 0, 1
 RT_FLAG_EXACT_ARITHMETIC = 1
 RT_FLAG_OBJECT_SPACE_SPHERES = 2
 RT_MAX_CSG_DEPTH = 8

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -206,9 +207,9 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
       return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: path mode needs 1 <= n_rays <= 65535, 0 <= max_depth <= 32766, roulette >= 0");
     if (cfg->n_rays > 1 && cfg->max_depth > 64)
       return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: max_depth > 64 is supported only with n_rays == 1");
-    if (cfg->rng_mode != RT_RNG_PER_SAMPLE_STREAMS)
+    if (cfg->rng_mode != RT_RNG_PER_NODE_STREAMS)
       return fail(RT_ERR_INVALID_ARGUMENT,
-                  "rt_render_cfg: the device renders path mode with per-sample streams only (RT_RNG_PER_SAMPLE_STREAMS)");
+                  "rt_render_cfg: the device renders path mode with per-sample streams only (RT_RNG_PER_NODE_STREAMS)");
   }
   if (cfg->mode == RT_MODE_POINTLIGHT && cfg->max_mirror_bounces <= 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_cfg: pointlight needs max_mirror_bounces > 0 (a lane must never spin)");
@@ -414,6 +415,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   const int spp2 = cfg->spp_edge * cfg->spp_edge;
   p.n_samples = n_pixels * static_cast<uint64_t>(spp2);
   p.counters = sc->counters;
+  p.sample_stride = 1;
+  if (p.n_samples > 2 && p.n_samples < (1ull << 31)) { // the product q * stride must fit 64 bits
+    uint64_t a = static_cast<uint64_t>(0.6180339887498949 * static_cast<double>(p.n_samples)) | 1ull;
+    while (std::gcd(a, p.n_samples) != 1)
+      a += 2;
+    p.sample_stride = a % p.n_samples;
+  }
 
   if (spp2 > 1) {
     if (rt_status st = ensure(sc->samples, p.n_samples * 3 * sizeof(float)))
@@ -424,6 +432,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   }
 
   constexpr int BLOCK = 256;
+  static_assert(BLOCK == rtd::PATH_THREADS, "k_render_path is launched with PATH_THREADS lanes");
   unsigned grid, block = BLOCK;
   const void *path_kernel = nullptr;
   if (cfg->mode == RT_MODE_PATH) {
@@ -448,11 +457,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     per_cu = std::max(per_cu, 1);
     const uint64_t want = (p.n_samples + block - 1) / block;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
-    p.n_lanes = grid * block;
-    p.stack_levels = cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1);
-    if (rt_status st = ensure(sc->stack, static_cast<size_t>(p.stack_levels) * rtd::STACK_WORDS * p.n_lanes * sizeof(float)))
+    // node stack of each workgroup: at most `block` nodes per depth level (rt_path.h)
+    p.pool_cap = static_cast<int32_t>(block) * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
+    if (rt_status st = ensure(sc->stack, static_cast<size_t>(grid) * rtd::NODE_WORDS * static_cast<size_t>(p.pool_cap) * sizeof(float)))
       return st;
-    p.stack = static_cast<float *>(sc->stack.ptr);
+    p.pool = static_cast<float *>(sc->stack.ptr);
   } else {
     const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 32));
@@ -483,6 +492,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     unsigned long long c[16];
     RT_HIP(hipMemcpy(c, sc->counters, sizeof c, hipMemcpyDeviceToHost));
 #ifdef RT_PROFILE_PHASES
+    std::fprintf(stderr, "[rt launch] grid=%u block=%u pool_cap=%d\n", grid, block, p.pool_cap);
     if (c[7])
       std::fprintf(stderr, "[rt phases] blocks*iters=%llu rays/iter=%.1f cycles/iter: queue=%.0f scan=%.0f shade=%.0f (100 MHz ticks x?)\n", c[7],
                    double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]));

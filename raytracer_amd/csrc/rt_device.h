@@ -105,13 +105,6 @@ RT_DEV uint64_t mix64(uint64_t z) { // splitmix64 finaliser
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-// Per-sample path stream (RT_RNG_PER_SAMPLE_STREAMS): depends only on (seq_number, global sample
-// index), so the image is identical for any GPU count.  Same derivation as oracle/rt_oracle.c.
-RT_DEV void sample_stream(Pcg &p, uint64_t seq_number, uint64_t global_sample) {
-  uint64_t init_state = mix64(global_sample ^ mix64(seq_number));
-  uint64_t init_seq = mix64(init_state);
-  pcg_init(p, init_state, init_seq);
-}
 
 // The AA generator is always PCG(42, 54) (ImageTracer ctor quirk, cameras.hpp:178-183); its state
 // after the constructor, advanced by 2k draws, gives sample k's jitter pair (cameras.hpp:232-233).
@@ -586,17 +579,30 @@ RT_DEV void onb_from_e3(V3 e3, V3 &e1, V3 &e2) {
 
 // DiffusiveBRDF::scatter_ray direction given the normalised normal — materials.hpp:199-211,
 // PCG::random_phong(1) — random.hpp:75-84
-RT_DEV V3 diffuse_scatter_dir(V3 e3, Pcg &pcg) {
+// FAST: the same direction without the round trip through the angles — cos(acos(sqrt x)) = sqrt x,
+// sin = sqrt(1 - x) — and sin/cos(2 pi y) from the hardware's v_sin_f32 / v_cos_f32, whose argument is
+// in revolutions.
+template <bool FAST> RT_DEV V3 diffuse_scatter_dir(V3 e3, Pcg &pcg) {
   V3 e1, e2;
   onb_from_e3(e3, e1, e2);
   float x = pcg_random_float(pcg);
-  // pow(x, 1.f/(n+1)) with n = 1 is x^(1/2): sqrtf is correctly rounded, which is what glibc's powf
-  // returns for this exponent (the device powf is not), so theta tracks the reference more closely.
-  float theta = acosf(sqrtf(x));
-  float phi = pcg_random_float(pcg) * 2 * PI_F;
-  float st = sinf(theta), ct = cosf(theta);
-  V3 a = scale3(scale3(e1, st), cosf(phi));
-  V3 b = scale3(scale3(e2, st), sinf(phi));
+  float y = pcg_random_float(pcg);
+  float st, ct, sp, cp;
+  if (FAST) {
+    ct = sqrtf(x);
+    st = sqrtf(fmaxf(1.f - x, 0.f));
+    sp = __builtin_amdgcn_sinf(y);
+    cp = __builtin_amdgcn_cosf(y);
+  } else {
+    // pow(x, 1.f/(n+1)) with n = 1 is x^(1/2): sqrtf is correctly rounded, which is what glibc's powf
+    // returns for this exponent (the device powf is not), so theta tracks the reference more closely.
+    float theta = acosf(sqrtf(x));
+    float phi = y * 2 * PI_F;
+    st = sinf(theta), ct = cosf(theta);
+    sp = sinf(phi), cp = cosf(phi);
+  }
+  V3 a = scale3(scale3(e1, st), cp);
+  V3 b = scale3(scale3(e2, st), sp);
   V3 c = scale3(e3, ct);
   return add3(add3(a, b), c);
 }

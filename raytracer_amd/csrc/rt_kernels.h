@@ -1,8 +1,7 @@
 // rt_kernels.h — the gfx950 kernels of the tracing loop.  One pixel-sample per lane.
 //
 //  k_render_simple<MODE>  onoff / flat / pointlight: grid-stride over the samples of this call's rows
-//  k_render_path          PathTracer as a per-lane explicit DFS with persistent lanes that refill
-//                         from a global sample counter (wave-aggregated atomic) when a sample ends
+//  k_render_path          PathTracer over a per-workgroup pool of recursion-tree nodes (rt_path.h)
 //  k_resolve              box filter: sum of a pixel's spp^2 samples in the reference's order, * 1/spp^2
 //  k_trace_rays / k_offset_if_visible / k_aa_jitter   batch parity entry points
 #pragma once
@@ -87,22 +86,23 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
   wave_add_counter(p.counters + 2, capped);
 }
 
-// Path kernel for small worlds: one ray per lane, every lane scans the (few) objects itself with
-// wave-uniform scalar record loads.  Persistent lanes refill from the call's sample queue.
-template <bool FAST> __global__ void __launch_bounds__(256) k_render_path(Scene s, RenderParams p) {
-  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
-  PathLane L;
-  L.init();
-  for (;;) {
-    L.refill(p);
-    if (!__any(L.active))
-      break;
-    if (L.active) {
-      const Hit h = world_ray_intersection<FAST>(s, L.ray);
-      L.shade_and_advance(s, p, h, lane_global);
-    }
+// Path kernel for small worlds: the workgroup's node pool deals one ray per lane (rt_path.h), every lane
+// scans the (few) objects itself with wave-uniform scalar record loads.
+constexpr int PATH_THREADS = 256;
+template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS) k_render_path(Scene s, RenderParams p) {
+  __shared__ PathShared<PATH_THREADS> sh;
+  PathBlock<PATH_THREADS, FAST> B;
+  B.init(p, sh);
+  while (B.deal(s, p, sh)) {
+    Hit h;
+    h.object = h.shape = -1;
+    h.t = 0.f;
+    h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+    if (B.active)
+      h = world_ray_intersection<FAST>(s, B.ray);
+    B.shade(s, p, sh, h);
   }
-  wave_add_counter(p.counters + 1, L.rays);
+  wave_add_counter(p.counters + 1, B.rays);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +179,7 @@ __global__ void k_scatter_rays(uint32_t brdf_kind, uint64_t *pcg, const float *i
     Pcg p;
     p.state = pcg[2 * i];
     p.inc = pcg[2 * i + 1];
-    d = diffuse_scatter_dir(normalized3(ld3(normal + 3 * i)), p);
+    d = diffuse_scatter_dir<false>(normalized3(ld3(normal + 3 * i)), p);
     pcg[2 * i] = p.state;
   }
   dir_out[3 * i + 0] = d.x;

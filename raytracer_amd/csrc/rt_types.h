@@ -103,12 +103,13 @@ struct RenderParams {
   float ambient[3];
   int32_t band_rows, band_stride, band_offset, n_local_rows;
   uint64_t n_samples;          // n_local_rows * width * spp_edge^2
+  uint64_t sample_stride;      // path mode: coprime to n_samples, about 0.618 n_samples (see rt_path.h)
   float *samples_out;          // [n_samples][3] (== framebuffer when spp_edge == 1)
   unsigned long long *counters; // [0] next sample, [1] rays, [2] capped samples
-  // path mode: per-lane DFS stack in HBM, SoA: word w of level l of lane g at stack[(l*STACK_WORDS + w)*n_lanes + g]
-  float *stack;
-  uint32_t n_lanes;
-  int32_t stack_levels;
+  // path mode: one node stack per workgroup in HBM, SoA: word w of node i of block b at
+  // pool[(b * NODE_WORDS + w) * pool_cap + i]   (rt_path.h)
+  float *pool;
+  int32_t pool_cap;
 };
 
 } // namespace rtd

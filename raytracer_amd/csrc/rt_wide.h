@@ -16,8 +16,9 @@ namespace rtd {
 //     A lane that finds a hit merges {t, object index} into the ray's 64-bit LDS key with one
 //     ds_min_u64: t > 0, so the float bits order like the numbers, and equal t falls to the lowest
 //     object index exactly as World::ray_intersection's strict `<` does.
-//   * Then every lane is a ray again: it completes the query (planes, CSG, hit record), shades the
-//     node and produces the next ray of its sample.
+//   * Then every lane is a ray again: it completes the query (planes, CSG, hit record) and shades the
+//     node; scattering hits push their node onto the workgroup's pool (rt_path.h), which deals the
+//     next rays.
 //
 //   ISO: all spheres are translation * uniform scaling, tested in world space from (centre, r^2):
 //        oc = O - C; b = oc.D; c = oc.oc - r^2; disc = b^2 - (D.D) c      (12 VALU per test)
@@ -102,8 +103,8 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
   __shared__ WideRay q_ray[WIDE_THREADS];
   __shared__ unsigned long long q_key[WIDE_THREADS];
   __shared__ int q_count;
+  __shared__ PathShared<WIDE_THREADS> sh;
 
-  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // Spheres [wide_first, n_spheres) are held in registers as n_rows full rows of 64; the first
   // wide_first (< 64) spheres of the list are scanned per lane with the other objects.  Row r of a
@@ -111,8 +112,8 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
   const int wide_first = s.n_spheres % 64;
   const int n_rows = s.n_spheres / 64;
   const int n_pass = (n_rows + K * WIDE_WAVES - 1) / (K * WIDE_WAVES);
-  PathLane L;
-  L.init();
+  PathBlock<WIDE_THREADS, true> L;
+  L.init(p, sh);
   WideSlots<ISO, K> slots;
   if (n_pass == 1) { // the whole world fits: load the registers once
 #pragma unroll
@@ -128,11 +129,11 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
 #endif
   for (;;) {
     RT_STAMP(ts0);
-    // -- every lane is a sample: refill, then queue the live rays (compacted) ----------------------
+    // -- every lane gets a ray from the workgroup's node pool; the live rays are queued (compacted) ----
     if (threadIdx.x == 0)
       q_count = 0;
-    L.refill(p);
-    __syncthreads();
+    if (!L.deal(s, p, sh)) // synchronises the workgroup
+      break;
     int my_q = -1;
     if (L.active) {
       const unsigned long long live = __ballot(1);
@@ -153,8 +154,6 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
     }
     __syncthreads();
     const int n_q = q_count;
-    if (n_q == 0)
-      break; // no live sample in the workgroup and the call's queue is drained
     RT_STAMP(ts1);
 
     // -- every lane is K spheres: all waves test every queued ray ----------------------------------
@@ -223,6 +222,10 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
     RT_STAMP(ts2);
 
     // -- every lane is a ray again: finish the query, shade, produce the next ray -------------------
+    Hit h;
+    h.object = h.shape = -1;
+    h.t = 0.f;
+    h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
     if (L.active) {
       const unsigned long long key = q_key[my_q];
       Best best;
@@ -239,10 +242,9 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
           best.shape = s.spheres[sphere].shape;
         }
       }
-      const Hit h = world_finish_hit(s, L.ray, best);
-      L.shade_and_advance(s, p, h, lane_global);
+      h = world_finish_hit(s, L.ray, best);
     }
-    __syncthreads(); // q_count / q_ray are rewritten at the top
+    L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
 #ifdef RT_PROFILE_PHASES
     RT_STAMP(ts3);
     t_queue += ts1 - ts0, t_scan += ts2 - ts1, t_shade += ts3 - ts2, n_iter += 1, n_rays_q += n_q;

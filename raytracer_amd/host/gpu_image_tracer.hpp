@@ -85,7 +85,7 @@ public:
     cfg.background[0] = mode.background.r, cfg.background[1] = mode.background.g, cfg.background[2] = mode.background.b;
     cfg.ambient[0] = mode.ambient.r, cfg.ambient[1] = mode.ambient.g, cfg.ambient[2] = mode.ambient.b;
     cfg.max_mirror_bounces = mode.max_mirror_bounces;
-    cfg.rng_mode = RT_RNG_PER_SAMPLE_STREAMS;
+    cfg.rng_mode = RT_RNG_PER_NODE_STREAMS;
     static_assert(sizeof(Color) == 3 * sizeof(float), "HdrImage::pixels must be packed rgb floats");
     float *pixels = reinterpret_cast<float *>(image->pixels.data());
     last_stats = rt_stats{};

@@ -143,7 +143,7 @@ class GpuImageTracer:
         cfg.background[:] = mode.background
         cfg.ambient[:] = mode.ambient
         cfg.max_mirror_bounces = mode.max_mirror_bounces
-        cfg.rng_mode = abi.RT_RNG_PER_SAMPLE_STREAMS
+        cfg.rng_mode = abi.RT_RNG_PER_NODE_STREAMS
         cfg.band_rows, cfg.band_stride, cfg.band_offset = rows.band_rows, rows.band_stride, rows.band_offset
         cfg.n_local_rows = rows.n_local_rows
         cfg.flags = (abi.RT_FLAG_EXACT_ARITHMETIC if mode.exact else 0) | \

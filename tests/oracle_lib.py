@@ -32,7 +32,8 @@ _PROTOS = {
     "rto_pcg_random": (C.c_uint32, [_u64x2]),
     "rto_pcg_random_float": (C.c_float, [_u64x2]),
     "rto_pcg_advance": (None, [_u64x2, C.c_uint64]),
-    "rto_sample_stream": (None, [_u64x2, C.c_uint64, C.c_uint64]),
+    "rto_node_root_stream": (None, [_u64x2, C.c_uint64, C.c_uint64]),
+    "rto_node_child_stream": (None, [_u64x2, C.c_uint32]),
     "rto_aa_jitter": (None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rto_scatter_ray": (None, [C.c_int, _u64x2, _f3, _f3, _f3, C.c_int, C.POINTER(abi.rt_ray)]),
     "rto_pigment": (None, [C.POINTER(abi.rt_scene_desc), C.c_uint32, C.c_float, C.c_float, _f3]),
@@ -62,7 +63,7 @@ def dll():
 
 def make_cfg(width, height, mode="flat", spp_edge=1, n_rays=10, roulette=3, max_depth=5, seq_number=54,
              background=(0, 0, 0), ambient=(0.1, 0.1, 0.1), max_mirror_bounces=64,
-             rng_mode=abi.RT_RNG_PER_SAMPLE_STREAMS, band_rows=None, band_stride=None, band_offset=0,
+             rng_mode=abi.RT_RNG_PER_NODE_STREAMS, band_rows=None, band_stride=None, band_offset=0,
              n_local_rows=None) -> abi.rt_render_cfg:
     cfg = abi.rt_render_cfg()
     cfg.width, cfg.height, cfg.spp_edge = width, height, spp_edge

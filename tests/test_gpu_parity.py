@@ -154,7 +154,7 @@ def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, ro
     img, stats = gpu_render(worlds, scenes, scene, "path", w, h, aa, n_rays=n_rays, roulette=roulette, max_depth=max_depth,
                             seq_number=seq, exact=exact)
     cfg = O.make_cfg(w, h, "path", spp_edge=aa, n_rays=n_rays, roulette=roulette, max_depth=max_depth, seq_number=seq,
-                     rng_mode=abi.RT_RNG_PER_SAMPLE_STREAMS)
+                     rng_mode=abi.RT_RNG_PER_NODE_STREAMS)
     want, ostats = O.render(scenes[scene], cfg)
     diff = np.abs(img - want).max(axis=-1)
     outliers = diff > 1e-4
@@ -261,7 +261,7 @@ def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
     exact = tr.fire_all_rays(world, RenderMode("path", exact=True, **kw))  # the per-lane kernel, unfused arithmetic
     objsp = tr.fire_all_rays(world, RenderMode("path", object_space_spheres=True, **kw))  # wide kernel, object-space form
     world.close()
-    want, ostats = O.render(scene, O.make_cfg(w, h, "path", spp_edge=aa, rng_mode=abi.RT_RNG_PER_SAMPLE_STREAMS, **kw))
+    want, ostats = O.render(scene, O.make_cfg(w, h, "path", spp_edge=aa, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))
     for name, got in (("wide", img), ("wide-object-space", objsp), ("exact", exact)):
         diff = np.abs(got - want).max(axis=-1)
         outliers = diff > 1e-4

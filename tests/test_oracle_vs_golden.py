@@ -44,7 +44,7 @@ def test_onoff_c1_mask_bit_identical(scenes):
     ("flat_demo_path_clock30_160x120_aa1", "demo_path_clock30", "flat", 160, 120, 1),
 ])
 def test_deterministic_modes_bit_identical(golden_images, scenes, key, scene, mode, w, h, aa):
-    for rng_mode in (SERIAL, abi.RT_RNG_PER_SAMPLE_STREAMS):  # AA jitter: serial draw order == jump-ahead
+    for rng_mode in (SERIAL, abi.RT_RNG_PER_NODE_STREAMS):  # AA jitter: serial draw order == jump-ahead
         img, _ = O.render(scenes[scene], O.make_cfg(w, h, mode, spp_edge=aa, rng_mode=rng_mode, max_mirror_bounces=64))
         assert np.array_equal(img, golden_images[key]), key
 
