@@ -330,6 +330,11 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, planes, &S.planes));
   UP(upload(sc, cb.tops, &S.csg_tops));
   S.n_spheres = static_cast<int32_t>(spheres.size());
+  // A leftover of 16 or more spheres is cheaper as one more (partly empty) register row (11 wave instructions
+  // per ray) than scanned lane by lane (33 instructions per sphere and lane).
+  const int leftover = S.n_spheres % 64;
+  S.wide_first = leftover >= 16 ? 0 : leftover;
+  S.wide_rows = (S.n_spheres - S.wide_first + 63) / 64;
   S.n_planes = static_cast<int32_t>(planes.size());
   S.n_csg_tops = static_cast<int32_t>(cb.tops.size());
   S.n_objects = static_cast<int32_t>(d->n_objects);
@@ -439,8 +444,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
-    const int rows = sc->dev.n_spheres / 64;
-    if (!exact && rows >= 1) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
+    const int rows = sc->dev.wide_rows;
+    if (!exact && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
       const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.

@@ -89,7 +89,7 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
 // Path kernel for small worlds: the workgroup's node pool deals one ray per lane (rt_path.h), every lane
 // scans the (few) objects itself with wave-uniform scalar record loads.
 constexpr int PATH_THREADS = 256;
-template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS) k_render_path(Scene s, RenderParams p) {
+template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS, 4) k_render_path(Scene s, RenderParams p) {
   __shared__ PathShared<PATH_THREADS> sh;
   PathBlock<PATH_THREADS, FAST> B;
   B.init(p, sh);

@@ -49,6 +49,9 @@ struct CsgProgEntry {  // RPN program "is point inside this subtree?"
 struct Scene {
   // scan lists
   const ScanRec *spheres; int32_t n_spheres;
+  // wide path kernel: spheres [wide_first, n_spheres) are held in registers as wide_rows rows of 64 (the last
+  // row may be partly empty), the first wide_first ones are scanned per lane (rt_wide.h)
+  int32_t wide_first, wide_rows;
   const float *sphere_iso;        // [n_spheres][4] world centre + r^2, valid iff spheres_all_iso
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   const ScanRec *planes;  int32_t n_planes;

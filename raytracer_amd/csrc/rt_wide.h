@@ -94,6 +94,49 @@ template <int K> struct WideSlots<false, K> {
   }
 };
 
+// One queued ray against a lane's K spheres.  The K discriminants are one straight-line block (no branch
+// per sphere); the rare hit work sits behind a single wave-level branch.  A hit merges into the ray's key.
+template <bool ISO, int K, int W>
+RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRay &r, unsigned long long *key_slot, int first, int wave, int lane) {
+  float disc[K], b[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    disc[k] = slots.disc(k, r, b[k]);
+  float dmax = disc[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k)
+    dmax = fmaxf(dmax, disc[k]);
+  if (dmax > 0.f) {
+    float best_t = INF_F;
+    int best_k = -1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (disc[k] > 0.f) {
+        float inv_a;
+        slots.a_of(k, r, inv_a);
+        const float sq = sqrtf(disc[k]);
+        const float t1 = (-b[k] - sq) * inv_a;
+        const float t2 = (-b[k] + sq) * inv_a;
+        float t = t1;
+        bool ok = true;
+        if (t1 < r.tmin) {
+          t = t2;
+          ok = t2 > r.tmin && t2 < r.tmax;
+        }
+        if (ok && t < best_t) { // ascending k = ascending object index within a lane
+          best_t = t;
+          best_k = k;
+        }
+      }
+    }
+    if (best_k >= 0) {
+      const int sphere = first + (best_k * W + wave) * 64 + lane;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)sphere;
+      atomicMin(key_slot, key);
+    }
+  }
+}
+
 // Register budget: ISO rows cost 4 VGPRs, general rows 13.  Where the rows leave room, ask for 4 waves per
 // SIMD (<= 128 VGPRs), so that several workgroups share a CU and one's shading overlaps another's scan.
 template <bool ISO, int K, int W>
@@ -106,20 +149,15 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
   __shared__ PathShared<WIDE_THREADS> sh;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // Spheres [wide_first, n_spheres) are held in registers as n_rows full rows of 64; the first
-  // wide_first (< 64) spheres of the list are scanned per lane with the other objects.  Row r of a
+  // Spheres [wide_first, n_spheres) are held in registers as n_rows rows of 64 (the last one may be partly
+  // empty); the first wide_first (< 16) spheres of the list are scanned per lane with the other objects.  Row r of a
   // pass belongs to wave r % W, register row r / W; rows past n_rows are never-hit dummies.
-  const int wide_first = s.n_spheres % 64;
-  const int n_rows = s.n_spheres / 64;
+  const int wide_first = s.wide_first;
+  const int n_rows = s.wide_rows;
   const int n_pass = (n_rows + K * WIDE_WAVES - 1) / (K * WIDE_WAVES);
   PathBlock<WIDE_THREADS, true> L;
   L.init(p, sh);
   WideSlots<ISO, K> slots;
-  if (n_pass == 1) { // the whole world fits: load the registers once
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-      slots.load(s, k, wide_first + (k * WIDE_WAVES + wave) * 64 + lane, k * WIDE_WAVES + wave < n_rows);
-  }
 
 #ifdef RT_PROFILE_PHASES
   unsigned long long t_queue = 0, t_scan = 0, t_shade = 0, n_iter = 0, n_rays_q = 0;
@@ -159,52 +197,12 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
     // -- every lane is K spheres: all waves test every queued ray ----------------------------------
     for (int pass = 0; pass < n_pass; ++pass) {
       const int first = wide_first + pass * K * WIDE_WAVES * 64;
-      if (n_pass > 1) {
+      // (Re)load this pass's spheres: 16 bytes per sphere from L2, once per iteration — cheaper than keeping
+      // K rows alive across the shading phase, where they would push its working set out of the register file.
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, (pass * K + k) * WIDE_WAVES + wave < n_rows);
-      }
-      // One queued ray against this lane's K spheres.  The K discriminants are one straight-line block
-      // (no branch per sphere); the rare hit work sits behind a single wave-level branch.
-      auto test_ray = [&](const WideRay &r, int qi) {
-        float disc[K], b[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          disc[k] = slots.disc(k, r, b[k]);
-        float dmax = disc[0];
-#pragma unroll
-        for (int k = 1; k < K; ++k)
-          dmax = fmaxf(dmax, disc[k]);
-        if (dmax > 0.f) {
-          float best_t = INF_F;
-          int best_k = -1;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            if (disc[k] > 0.f) {
-              float inv_a;
-              slots.a_of(k, r, inv_a);
-              const float sq = sqrtf(disc[k]);
-              const float t1 = (-b[k] - sq) * inv_a;
-              const float t2 = (-b[k] + sq) * inv_a;
-              float t = t1;
-              bool ok = true;
-              if (t1 < r.tmin) {
-                t = t2;
-                ok = t2 > r.tmin && t2 < r.tmax;
-              }
-              if (ok && t < best_t) { // ascending k = ascending object index within a lane
-                best_t = t;
-                best_k = k;
-              }
-            }
-          }
-          if (best_k >= 0) {
-            const int sphere = first + (best_k * WIDE_WAVES + wave) * 64 + lane;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned)sphere;
-            atomicMin(&q_key[qi], key);
-          }
-        }
-      };
+      for (int k = 0; k < K; ++k)
+        slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, first + (k * WIDE_WAVES + wave) * 64 + lane < s.n_spheres);
+      auto test_ray = [&](const WideRay &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
       // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
       // the lanes test the current one.
       WideRay ra = q_ray[0];

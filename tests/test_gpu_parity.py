@@ -225,7 +225,9 @@ def test_error_behaviour(worlds, scenes):
         DeviceWorld(broken)
 
 
-# ---- the wide path kernel (worlds with >= 512 top-level spheres: spheres in registers, rays through LDS) ----
+# ---- the wide path kernel (worlds with >= 64 top-level spheres: spheres in registers, rays through LDS) ----
+# sphere counts cover: leftover scanned per lane (77 -> 78 = 64 + 14), partly empty last row (100, 90), several waves
+# per workgroup (1100: 2 waves, 4000: 8 waves)
 
 def _ellipsoid_world(n, seed=5):
     """n random ellipsoids (rotated, non-uniformly scaled: the general affine register form) + floor + sky."""
@@ -247,7 +249,7 @@ def _ellipsoid_world(n, seed=5):
     return b.build()
 
 
-@pytest.mark.parametrize("kind,n", [("iso", 600), ("iso", 1100), ("general", 700)])
+@pytest.mark.parametrize("kind,n", [("iso", 600), ("iso", 1100), ("general", 700), ("iso", 77), ("iso", 100), ("general", 90), ("iso", 4000)])
 def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
     """Same per-sample streams on the wide kernel and on the CPU oracle -> the same paths (FMA / world-space
     sphere arithmetic moves t by ulps, so a few paths diverge at discontinuities)."""
@@ -266,8 +268,12 @@ def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
         diff = np.abs(got - want).max(axis=-1)
         outliers = diff > 1e-4
         print(f"{kind} n={n} {name}: {int(outliers.sum())} of {outliers.size} pixels differ by > 1e-4 (max {diff.max():.3g})")
-        assert outliers.mean() <= 0.10
-        assert abs(float(got.mean()) - float(want.mean())) <= 0.01 * float(want.mean())
+        # the unfused kernel follows the oracle's paths except for libm-ulp effects; the FMA kernels leave them where a
+        # hit decision flips, the more often the more spheres a path meets (n=600: 2 %, 1100: 6 %, 4000: 17 %)
+        limit = 0.03 if name == "exact" else (0.10 if n < 2000 else 0.25)
+        assert outliers.mean() <= limit
+        # diverged pixels are other samples of the same estimator: the 960-pixel mean moves by ~sqrt(#diverged) * 0.3 / 960
+        assert abs(float(got.mean()) - float(want.mean())) <= (0.01 if n < 2000 else 0.03) * float(want.mean())
     assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
 
 

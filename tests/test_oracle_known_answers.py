@@ -605,3 +605,48 @@ def test_gpu_path_tracer_furnace(gpu):
         w.close()
         assert t.last_stats.rays == 201
         assert close(img[0, 0], (luminosity / (np.float32(1) - reflectance), 0, 0), 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# RT_RNG_PER_NODE_STREAMS (ours: one stream per ray) must be the same estimator as the reference's serial PCG
+# ---------------------------------------------------------------------------------------------------
+def test_furnace_with_node_streams():
+    """The furnace identity holds whatever the random numbers are, so it pins the node-stream evaluation
+    (throughput form + fixed-point accumulation) of the oracle to 2^-32-level accuracy."""
+    cam = Camera(abi.RT_CAMERA_ORTHOGONAL, translation((1, 0, 0)), 1.0)   # fires Ray{(0,0,0), VEC_X}
+    cfg = O.make_cfg(1, 1, "path", n_rays=1, roulette=200, max_depth=200)
+    for reflectance, luminosity in furnace_cases(20):
+        img, st = O.render(furnace_world(reflectance, luminosity), cfg, cam)
+        assert st.rays == 201
+        assert close(img[0, 0], (luminosity / (np.float32(1) - reflectance), 0, 0), 2e-5)
+
+
+def test_node_streams_agree_with_serial_reference_statistically(scenes, golden_images):
+    """Same scene, same settings: the node-stream image and the reference's serial-PCG image (golden, 36 spp) are two
+    independent estimates of one mean.  Their difference must look like Monte-Carlo noise: image means within 1 %,
+    and the mean squared difference no larger than the sum of the two estimators' variances (measured from
+    independent node-stream renders with other seq_numbers)."""
+    scene = scenes["demo_path"]
+    ref = golden_images["path_demo_path_96x72_aa6_serial"].astype(np.float64)
+    imgs = [O.render(scene, O.make_cfg(96, 72, "path", spp_edge=6, seq_number=s))[0].astype(np.float64) for s in (54, 55, 56)]
+    a, b, c = imgs
+    var_one = 0.5 * np.mean((b - c) ** 2)                 # variance of one 36-spp estimate, image average
+    mse = np.mean((a - ref) ** 2)                         # ~ 2 * var_one if both are unbiased
+    assert abs(a.mean() - ref.mean()) < 0.01 * ref.mean()
+    assert mse < 2.6 * var_one, (mse, var_one)
+    assert mse > 1.4 * var_one, (mse, var_one)            # and they are not the same stream in disguise
+
+
+def test_node_stream_keys_are_distinct():
+    st = O._u64x2()
+    seen = set()
+    for g in range(64):
+        O.dll().rto_node_root_stream(st, 54, g)
+        root = st[0]
+        assert st[1] == 109
+        for k in range(10):
+            st[0] = root
+            O.dll().rto_node_child_stream(st, k)
+            seen.add(st[0])
+        seen.add(root)
+    assert len(seen) == 64 * 11
