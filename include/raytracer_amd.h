@@ -264,6 +264,41 @@ RT_API rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n
 RT_API rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const float *in_dir,
                                  const float *normal, size_t n, float *dir_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Tone-mapping tail: what main() does with the rendered HdrImage before it writes the PNG
+ * (src/raytracer.cpp:176-186) — HdrImage::normalize_image, clamp_image and the per-component
+ * transform of write_ldr_image (include/colors.hpp:469-516), on the framebuffer while it is still
+ * in HBM, so that a PNG-only run copies 3 bytes per pixel to the host instead of 12.
+ * ------------------------------------------------------------------------------------------ */
+/* Accumulate the log-luminosities in the reference's pixel order in binary32 (one wave, same roundings
+ * as HdrImage::average_luminosity's serial loop); default: exact sum in 64-bit fixed point. */
+#define RT_TONEMAP_SERIAL_SUM 1u
+
+typedef struct rt_tonemap_cfg {
+  float alpha;                 /* --alpha: normalize_image's factor */
+  float gamma;                 /* --gamma */
+  uint32_t has_avg_luminosity; /* 1: use avg_luminosity (dark mode, src/raytracer.cpp:180) */
+  float avg_luminosity;
+  float delta;                 /* DEFAULT_DELTA_LOG = 1e-10f (include/colors.hpp:41) */
+  uint32_t flags;              /* RT_TONEMAP_* */
+} rt_tonemap_cfg;
+
+/* HdrImage::average_luminosity (include/colors.hpp:469-476) of n_pixels rgb pixels in device memory. */
+RT_API rt_status rt_average_luminosity(int device, const float *rgb_device, size_t n_pixels, float delta,
+                                       uint32_t flags, void *stream, float *avg_out);
+
+/* normalize_image(alpha[, avg]) + clamp_image + pow(x, 1/gamma) * 255 rounded to 8 bits
+ * (include/colors.hpp:481-516).  ldr_out_device: 3 * n_pixels bytes, rgb, row 0 = top (the buffer
+ * write_ldr_image hands to stbi_write_png).  hdr_out_device: optional, the normalised and clamped
+ * floats (may alias rgb_device).  avg_used_out: optional, the average luminosity that was used.
+ * Float images must be 16-byte aligned and the 8-bit image 4-byte aligned (whole hipMalloc'ed buffers are). */
+RT_API rt_status rt_tonemap(int device, const float *rgb_device, size_t n_pixels, const rt_tonemap_cfg *cfg,
+                            uint8_t *ldr_out_device, float *hdr_out_device, void *stream, float *avg_used_out);
+
+/* The same with host buffers (copies in, copies the 8-bit image out). */
+RT_API rt_status rt_tonemap_host(int device, const float *rgb_host, size_t n_pixels, const rt_tonemap_cfg *cfg,
+                                 uint8_t *ldr_out_host, float *avg_used_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,7 +293,27 @@ int cmd_csg_ts(const Args &a) {
 
 } // namespace
 
+// tonemap <in.pfm> <out.bin> <alpha> [avg_luminosity]: the tail of main() after a render (src/raytracer.cpp:176-182):
+// HdrImage::normalize_image (with average_luminosity unless a value is given) + clamp_image, by the reference's
+// own methods.  out.bin = the normalised + clamped pixels (row 0 = top); stdout = the average luminosity used.
+int cmd_tonemap(int argc, char **argv) {
+  if (argc < 5)
+    die("tonemap <in.pfm> <out.bin> <alpha> [avg_luminosity]");
+  HdrImage img{std::string(argv[2])};
+  const float alpha = std::stof(argv[4]);
+  const float avg = argc > 5 ? std::stof(argv[5]) : img.average_luminosity();
+  img.normalize_image(alpha, avg);
+  img.clamp_image();
+  std::ofstream of(argv[3], std::ios::binary);
+  of.write(reinterpret_cast<const char *>(img.pixels.data()), static_cast<std::streamsize>(img.pixels.size() * sizeof(Color)));
+  std::cout.precision(9);
+  std::cout << "{\"avg_luminosity\": " << avg << ", \"width\": " << img.width << ", \"height\": " << img.height << "}" << std::endl;
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "tonemap")
+    return cmd_tonemap(argc, argv);
   Args a = parse_args(argc, argv);
   if (a.cmd == "render") return cmd_render(a);
   if (a.cmd == "flatten") return cmd_flatten(a);

@@ -916,3 +916,40 @@ RTO_EXPORT void rto_hom_apply(const float m[12], const float inv[12], int what, 
   else r = hom_apply_transposed(inv, a);
   out[0] = r.x, out[1] = r.y, out[2] = r.z;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Tone-mapping tail — include/colors.hpp:170-173, 87, 469-533; src/raytracer.cpp:176-186
+ * ------------------------------------------------------------------------------------------ */
+
+/* Color::luminosity — colors.hpp:170-173 */
+static float luminosity(const float *p) {
+  float mn = fminf(fminf(p[0], p[1]), p[2]), mx = fmaxf(fmaxf(p[0], p[1]), p[2]);
+  return 0.5f * (mn + mx);
+}
+
+/* HdrImage::average_luminosity — colors.hpp:469-476: serial binary32 sum in pixel order */
+RTO_EXPORT float rto_average_luminosity(const float *rgb, size_t n_pixels, float delta) {
+  float cumsum = 0.f;
+  for (size_t i = 0; i < n_pixels; ++i)
+    cumsum += log10f(delta + luminosity(rgb + 3 * i));
+  return powf(10.f, cumsum / (float)n_pixels);
+}
+
+/* normalize_image + clamp_image + write_ldr_image's per-component transform.  hdr_out (optional): the
+ * normalised and clamped floats; ldr_out (optional): the 8-bit components.  Returns the average used. */
+RTO_EXPORT float rto_tonemap(const float *rgb, size_t n_pixels, const rt_tonemap_cfg *cfg, float *hdr_out, uint8_t *ldr_out) {
+  const float avg = cfg->has_avg_luminosity ? cfg->avg_luminosity : rto_average_luminosity(rgb, n_pixels, cfg->delta);
+  const float scale = cfg->alpha / avg;
+  for (size_t i = 0; i < 3 * n_pixels; ++i) {
+    float v = rgb[i] * scale; /* colors.hpp:485-487 */
+    v = v / (1.f + v);        /* _clamp, colors.hpp:87 */
+    if (hdr_out)
+      hdr_out[i] = v;
+    if (ldr_out) {
+      float g = powf(v, 1.f / cfg->gamma); /* colors.hpp:514-515 */
+      float r = roundf(g * 255.f);
+      ldr_out[i] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+  }
+  return avg;
+}

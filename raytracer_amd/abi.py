@@ -88,6 +88,14 @@ HIT_DTYPE = _np.dtype([("object", "<i4"), ("shape", "<i4"), ("t", "<f4"), ("poin
 assert RAY_DTYPE.itemsize == C.sizeof(rt_ray) and HIT_DTYPE.itemsize == C.sizeof(rt_hit)
 
 # Every symbol include/raytracer_amd.h declares: name -> (restype, argtypes)
+RT_TONEMAP_SERIAL_SUM = 1
+
+
+class rt_tonemap_cfg(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("gamma", C.c_float), ("has_avg_luminosity", C.c_uint32), ("avg_luminosity", C.c_float),
+                ("delta", C.c_float), ("flags", C.c_uint32)]
+
+
 PROTOTYPES = {
     "rt_last_error": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
@@ -101,6 +109,10 @@ PROTOTYPES = {
     "rt_offset_if_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_aa_jitter": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rt_scatter_rays": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rt_average_luminosity": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]),
+    "rt_tonemap": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(rt_tonemap_cfg), C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.POINTER(C.c_float)]),
+    "rt_tonemap_host": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(rt_tonemap_cfg), C.c_void_p, C.POINTER(C.c_float)]),
 }
 
 

@@ -179,3 +179,54 @@ class GpuImageTracer:
         check(dll().rt_render(world.handle, C.byref(cam), C.byref(cfg), out.data_ptr(), stream, stats_p))
         self.last_stats = stats if want_stats else None
         return out
+
+
+# -- the tone-mapping tail (reference src/raytracer.cpp:176-186, include/colors.hpp:469-516) -------------------------
+DEFAULT_DELTA_LOG = 1e-10           # include/colors.hpp:41
+DEFAULT_AVG_LUMINOSITY_DARK_MODE = 0.1  # include/colors.hpp:43-44 (the value --dark-mode passes to normalize_image)
+
+
+def make_tonemap_cfg(alpha=0.18, gamma=2.2, avg_luminosity=None, delta=DEFAULT_DELTA_LOG, serial_sum=False) -> abi.rt_tonemap_cfg:
+    cfg = abi.rt_tonemap_cfg()
+    cfg.alpha, cfg.gamma, cfg.delta = alpha, gamma, delta
+    cfg.has_avg_luminosity = 0 if avg_luminosity is None else 1
+    cfg.avg_luminosity = 0.0 if avg_luminosity is None else float(avg_luminosity)
+    cfg.flags = abi.RT_TONEMAP_SERIAL_SUM if serial_sum else 0
+    return cfg
+
+
+def average_luminosity(image, delta=DEFAULT_DELTA_LOG, serial_sum=False, stream=None) -> float:
+    """HdrImage::average_luminosity of a float32 [H, W, 3] CUDA/HIP tensor (stays in HBM)."""
+    import torch
+    if not (image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and image.shape[-1] == 3):
+        raise ValueError("image must be a contiguous float32 CUDA tensor [..., 3]")
+    if stream is None:
+        stream = torch.cuda.current_stream(image.device).cuda_stream
+    avg = C.c_float()
+    check(dll().rt_average_luminosity(image.device.index, image.data_ptr(), image.numel() // 3, delta,
+                                      abi.RT_TONEMAP_SERIAL_SUM if serial_sum else 0, stream, C.byref(avg)))
+    return avg.value
+
+
+def tonemap(image, alpha=0.18, gamma=2.2, avg_luminosity=None, serial_sum=False, want_hdr=False, stream=None):
+    """normalize_image + clamp_image + 8-bit gamma transform.
+
+    image: float32 [H, W, 3] — a CUDA/HIP tensor (result: uint8 tensor on the same device, nothing leaves HBM) or a numpy
+    array (host round trip through rt_tonemap_host).  Returns (ldr uint8 [H, W, 3], average luminosity used[, hdr])."""
+    cfg = make_tonemap_cfg(alpha, gamma, avg_luminosity, serial_sum=serial_sum)
+    avg = C.c_float()
+    if isinstance(image, np.ndarray):
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        ldr = np.empty(img.shape, dtype=np.uint8)
+        check(dll().rt_tonemap_host(0, img.ctypes.data, img.size // 3, C.byref(cfg), ldr.ctypes.data, C.byref(avg)))
+        return ldr, avg.value
+    import torch
+    if not (image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and image.shape[-1] == 3):
+        raise ValueError("image must be a contiguous float32 CUDA tensor [..., 3]")
+    if stream is None:
+        stream = torch.cuda.current_stream(image.device).cuda_stream
+    ldr = torch.empty(image.shape, dtype=torch.uint8, device=image.device)
+    hdr = torch.empty_like(image) if want_hdr else None
+    check(dll().rt_tonemap(image.device.index, image.data_ptr(), image.numel() // 3, C.byref(cfg), ldr.data_ptr(),
+                           hdr.data_ptr() if want_hdr else None, stream, C.byref(avg)))
+    return (ldr, avg.value, hdr) if want_hdr else (ldr, avg.value)

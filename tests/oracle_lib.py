@@ -43,6 +43,8 @@ _PROTOS = {
     "rto_shade": (C.c_int, [C.POINTER(abi.rt_scene_desc), C.POINTER(abi.rt_render_cfg), C.POINTER(abi.rt_ray), C.c_int,
                             _u64x2, _f3, C.POINTER(C.c_uint64)]),
     "rto_hom_apply": (None, [C.c_float * 12, C.c_float * 12, C.c_int, _f3, _f3]),
+    "rto_average_luminosity": (C.c_float, [C.c_void_p, C.c_size_t, C.c_float]),
+    "rto_tonemap": (C.c_float, [C.c_void_p, C.c_size_t, C.POINTER(abi.rt_tonemap_cfg), C.c_void_p, C.c_void_p]),
 }
 
 _dll = None
@@ -225,3 +227,21 @@ def read_pfm(path) -> np.ndarray:
     dt = "<f4" if float(endian) < 0 else ">f4"
     a = np.frombuffer(body, dtype=dt, count=w * h * 3).reshape(h, w, 3)
     return np.ascontiguousarray(a[::-1]).astype(np.float32)
+
+
+def average_luminosity(image: np.ndarray, delta=1e-10) -> float:
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    return dll().rto_average_luminosity(img.ctypes.data, img.size // 3, delta)
+
+
+def tonemap(image: np.ndarray, alpha=0.18, gamma=2.2, avg_luminosity=None, delta=1e-10):
+    """-> (ldr uint8, hdr float32 (normalised + clamped), average luminosity used)"""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    cfg = abi.rt_tonemap_cfg()
+    cfg.alpha, cfg.gamma, cfg.delta = alpha, gamma, delta
+    cfg.has_avg_luminosity = 0 if avg_luminosity is None else 1
+    cfg.avg_luminosity = 0.0 if avg_luminosity is None else float(avg_luminosity)
+    ldr = np.empty(img.shape, dtype=np.uint8)
+    hdr = np.empty(img.shape, dtype=np.float32)
+    avg = dll().rto_tonemap(img.ctypes.data, img.size // 3, C.byref(cfg), hdr.ctypes.data, ldr.ctypes.data)
+    return ldr, hdr, avg
