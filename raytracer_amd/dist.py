@@ -55,3 +55,18 @@ def gather_rows(local: torch.Tensor, height: int, full_out: torch.Tensor | None,
         return full_out
     dist.gather(padded, gather_list=None, dst=0)
     return None
+
+
+# -- animation batches ---------------------------------------------------------------------------
+def frames_for_rank(n_frames: int, rank: int, world: int) -> range:
+    """Frame-per-GPU parallelism for an animation (the reference's scripts/generate_image.sh loop over
+    `--define-float clock=...`): frames are dealt round-robin, every rank keeps ONE flattened scene in HBM and only the
+    camera changes from frame to frame (samples/demo_path_tracing.txt:3,40 — `rotation_z(clock) * translation(...)`)."""
+    return range(rank, n_frames, world)
+
+
+def orbit_camera(base, clock_degs: float):
+    """The camera of the reference's animation: rotation_z(clock) * <camera transformation of the scene at clock = 0>,
+    composed in binary32 exactly as the scene parser does (include/scenefiles.hpp:731-785)."""
+    from .scene import Camera, compose, degs_to_rads, rotation_z
+    return Camera(base.kind, compose(rotation_z(degs_to_rads(clock_degs)), base.transformation), base.asp_ratio, base.distance)
