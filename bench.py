@@ -44,6 +44,22 @@ def flops_per_ray(n_spheres_top: int, n_planes_top: int) -> float:
     return 52.0 * n_spheres_top + 7.0 + 35.0 * n_planes_top + 54.0 + 75.0
 
 
+def pmc_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed counter passes of THIS configuration
+    (scripts/pmc_run.sh -> profiles/r1/e_pool_n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the run's two
+    launches, each in its own rocprofv3 --pmc pass).  FETCH_SIZE is taken as reported (gfx950 tallies 64 B per 128-B
+    request for wide streaming reads; the node-stack reads here are dword gathers, uncalibrated).  None for any other
+    configuration: counters cannot be read from inside the timed run."""
+    default = (args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
+               and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
+    path = os.path.join(ROOT, "profiles", "r1", "e_pool_n512_pmc.json")
+    if not default or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        c = json.load(f)["counters"]
+    return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / 2.0
+
+
 def cpu_baseline(scene, text, args):
     """Times the CPU on a bounded sample of the same workload: the synthetic scene at a small resolution.
     kind "reference": the unmodified reference (oracle/_ref/rt_ref, single-threaded by construction); the
@@ -216,7 +232,7 @@ def main():
                        "parallelism": f"row-bands16x{world_size}" if world_size > 1 else "single"},
             "kernel_ms_per_step_max_rank": kernel_ms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": pmc_traffic(args),
                          "kernel": "rtd::k_render_path_wide<ISO,K,W> (+ k_resolve, <0.1 %)", "flops_per_ray": f_ray,
                          "rays_per_launch": rays_local, "kernel_ms": kernel_ms,
                          "executed_tflops": executed, "executed_frac": executed / FP32_VALU_PEAK_TFLOPS,
