@@ -595,7 +595,10 @@ static col3 shade_path(ctx_t *c, ray_t ray) {
  * * (1/n_rays) * rho(parent).  Contributions are summed in 64-bit fixed point (2^-32), which makes the
  * sum independent of the order of the nodes.  Children deeper than max_depth are BLACK without a
  * query (renderers.hpp:210), so they are not created. */
-static int64_t to_fixed(float x) { return (int64_t)((double)x * 4294967296.0); }
+static int64_t to_fixed(float x) { /* |x| clamped below 2^31 so that the device's fp64-free form gives the same integer */
+  x = fminf(fmaxf(x, -2147483520.f), 2147483520.f);
+  return (int64_t)((double)x * 4294967296.0);
+}
 static float from_fixed(int64_t a) { return (float)((double)a * (1.0 / 4294967296.0)); }
 
 static void shade_path_nodes(ctx_t *c, ray_t ray, pcg_t pcg, col3 throughput, int64_t acc[3]) {

@@ -36,6 +36,34 @@ RT_DEV V3 normalized3(V3 a) {
   return mk3(a.x / n, a.y / n, a.z / n);
 }
 
+// Fast variants for the FMA path tracer (statistical parity bar): reciprocal square root and fused transforms.
+RT_DEV V3 normalized3_fast(V3 a) {
+  const float inv = __builtin_amdgcn_rsqf(fmaf(a.x, a.x, fmaf(a.y, a.y, a.z * a.z)));
+  return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+template <typename P> RT_DEV V3 hom_vec_fast(P m, V3 v) {
+  return mk3(fmaf(m[0], v.x, fmaf(m[1], v.y, m[2] * v.z)), fmaf(m[3], v.x, fmaf(m[4], v.y, m[5] * v.z)),
+             fmaf(m[6], v.x, fmaf(m[7], v.y, m[8] * v.z)));
+}
+template <typename P> RT_DEV V3 hom_point_fast(P m, V3 p) {
+  return mk3(fmaf(m[0], p.x, fmaf(m[1], p.y, fmaf(m[2], p.z, m[9]))), fmaf(m[3], p.x, fmaf(m[4], p.y, fmaf(m[5], p.z, m[10]))),
+             fmaf(m[6], p.x, fmaf(m[7], p.y, fmaf(m[8], p.z, m[11]))));
+}
+template <typename P> RT_DEV V3 hom_transposed_fast(P m, V3 n) {
+  return mk3(fmaf(m[0], n.x, fmaf(m[3], n.y, m[6] * n.z)), fmaf(m[1], n.x, fmaf(m[4], n.y, m[7] * n.z)),
+             fmaf(m[2], n.x, fmaf(m[5], n.y, m[8] * n.z)));
+}
+
+// x * 2^32 truncated toward zero — what (long long)((double)x * 4294967296.0) gives — without fp64: the integer part
+// and the fraction of |x| convert exactly.  |x| is clamped below 2^31 (oracle/rt_oracle.c clamps alike).
+RT_DEV long long to_fixed32(float x) {
+  const float ax = fminf(fabsf(x), 2147483520.f);
+  const uint32_t hi = (uint32_t)ax;                                // truncates
+  const uint32_t lo = (uint32_t)((ax - (float)hi) * 4294967296.f); // exact product, truncates
+  const long long v = (long long)(((unsigned long long)hi << 32) | lo);
+  return x < 0.f ? -v : v;
+}
+
 // HomMatrix::apply(Vec) / apply(Point) / apply_transposed(Normal) — geometry.hpp:379-400
 template <typename P> RT_DEV V3 hom_vec(P m, V3 v) {
   return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
@@ -203,6 +231,19 @@ RT_DEV void make_hit(const Scene &s, int shape, const Ray &ray_local, float t, V
   local = p;
   point = hom_point(s.shape_fwd + 12 * shape, p);
   normal = hom_transposed(s.shape_inv + 12 * shape, n); // Transformation * Normal — geometry.hpp:506
+}
+
+// The same record with fused transforms (FMA path tracer).
+RT_DEV void make_hit_fast(const Scene &s, int shape, const Ray &ray_world, float t, V3 &point, V3 &normal, V3 &local) {
+  const float *inv = s.shape_inv + 12 * shape;
+  const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+  const V3 p = mk3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z));
+  V3 n = (s.shape_kind[shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
+  const float sign = copysignf(1.0f, -fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z)));
+  n = scale3(n, sign);
+  local = p;
+  point = hom_point_fast(s.shape_fwd + 12 * shape, p);
+  normal = hom_transposed_fast(inv, n);
 }
 
 // Sphere::calculate_uv / Plane::calculate_uv — shapes.hpp:259-266, 365-367
@@ -426,11 +467,20 @@ template <bool FAST> RT_DEV void scan_spheres(const Scene &s, int n, const Ray &
 
 // Second half of World::ray_intersection (shapes.hpp:547-561) once the spheres have been scanned:
 // planes and CSG objects, ties to the lowest object index, full record for the winner only.
-RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
+template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
   for (int i = 0; i < s.n_planes; ++i) {
     const RecRegs r = load_rec(s.planes, i);
     float t;
-    if (plane_front_t(r, ray, t) && (t < best.t || (t == best.t && r.object() < best.object))) {
+    bool hit;
+    if (FAST) { // only the z row of the inverse matrix matters to Plane::ray_intersection
+      const float oz = fmaf(r[6], ray.o.x, fmaf(r[7], ray.o.y, fmaf(r[8], ray.o.z, r[11])));
+      const float dz = fmaf(r[6], ray.d.x, fmaf(r[7], ray.d.y, r[8] * ray.d.z));
+      t = -oz * __builtin_amdgcn_rcpf(dz);
+      hit = !are_close(dz, 0.f) && !(t < ray.tmin || t > ray.tmax);
+    } else {
+      hit = plane_front_t(r, ray, t);
+    }
+    if (hit && (t < best.t || (t == best.t && r.object() < best.object))) {
       best.t = t;
       best.object = r.object();
       best.shape = r.shape();
@@ -455,11 +505,15 @@ RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
   if (best.shape < 0 && !csg_won)
     return h;
   if (!csg_won) {
-    Ray local = ray_transform(ray, s.shape_inv + 12 * best.shape);
     h.object = best.object;
     h.shape = best.shape;
     h.t = best.t;
-    make_hit(s, best.shape, local, best.t, h.point, h.normal, h.local);
+    if (FAST) {
+      make_hit_fast(s, best.shape, ray, best.t, h.point, h.normal, h.local);
+    } else {
+      Ray local = ray_transform(ray, s.shape_inv + 12 * best.shape);
+      make_hit(s, best.shape, local, best.t, h.point, h.normal, h.local);
+    }
   }
   return h;
 }
@@ -472,7 +526,7 @@ template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray
   best.object = 0x7fffffff;
   best.shape = -1;
   scan_spheres<FAST>(s, s.n_spheres, ray, best);
-  return world_finish_hit(s, ray, best);
+  return world_finish_hit<FAST>(s, ray, best);
 }
 
 // World::on_off_ray_intersection — shapes.hpp:567-578 (only the boolean is used, renderers.hpp:62-69)
@@ -612,6 +666,11 @@ RT_DEV V3 specular_scatter_dir(V3 in_dir, V3 normal) {
   in_dir = normalized3(in_dir);
   V3 n = normalized3(normal);
   return sub3(in_dir, scale3(scale3(n, 2.f), dot3(n, in_dir)));
+}
+RT_DEV V3 specular_scatter_dir_fast(V3 in_dir, V3 normal) {
+  const V3 d = normalized3_fast(in_dir), n = normalized3_fast(normal);
+  const float k = -2.f * fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z));
+  return mk3(fmaf(k, n.x, d.x), fmaf(k, n.y, d.y), fmaf(k, n.z, d.z));
 }
 
 } // namespace rtd

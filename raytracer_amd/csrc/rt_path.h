@@ -81,7 +81,7 @@ RT_DEV uint64_t node_child_key(uint64_t parent_state, uint32_t k) { // same in o
 RT_DEV uint64_t node_root_key(uint64_t seq_number, uint64_t global_sample) {
   return mix64(global_sample ^ mix64(seq_number));
 }
-RT_DEV long long to_fixed(float x) { return (long long)((double)x * 4294967296.0); }
+RT_DEV long long to_fixed(float x) { return to_fixed32(x); }
 RT_DEV float from_fixed(unsigned long long a) { return (float)((double)(long long)a * (1.0 / 4294967296.0)); }
 
 template <int T> struct PathShared { // LDS state of one workgroup
@@ -292,7 +292,10 @@ template <int T, bool FAST> struct PathBlock {
         push = push && depth < p.max_depth; // children deeper than max_depth are BLACK (renderers.hpp:210)
         if (push) {
           brdf = s.material_brdf[m];
-          vec = (brdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(ray.d, h.normal) : normalized3(h.normal);
+          if (FAST)
+            vec = (brdf == RT_BRDF_SPECULAR) ? specular_scatter_dir_fast(ray.d, h.normal) : normalized3_fast(h.normal);
+          else
+            vec = (brdf == RT_BRDF_SPECULAR) ? specular_scatter_dir(ray.d, h.normal) : normalized3(h.normal);
           weight = mul3(scale3(throughput, 1.f / (float)p.n_rays), reflected);
         }
       }

@@ -14,16 +14,6 @@ RT_DEV float log_luminosity(const float *px, float delta) {
   return log10f(delta + lum);
 }
 
-// x * 2^32 truncated toward zero, as (long long)((double)x * 4294967296.0) gives it, without fp64: the integer part
-// and the fraction of |x| convert exactly (|x| < 2^31).
-RT_DEV long long to_fixed32(float x) {
-  const float ax = fabsf(x);
-  const uint32_t hi = (uint32_t)ax;                                // truncates
-  const uint32_t lo = (uint32_t)((ax - (float)hi) * 4294967296.f); // exact product, truncates
-  const long long v = (long long)(((unsigned long long)hi << 32) | lo);
-  return x < 0.f ? -v : v;
-}
-
 // Exact sum of the terms in 64-bit fixed point (2^-32): independent of the order of the additions.  Four pixels
 // (48 contiguous bytes, three 16-byte loads) per lane and step.
 __global__ void __launch_bounds__(256) k_log_luminosity_sum(const float *rgb, size_t n_pixels, float delta, unsigned long long *sum) {

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
           best.shape = s.spheres[sphere].shape;
         }
       }
-      h = world_finish_hit(s, L.ray, best);
+      h = world_finish_hit<true>(s, L.ray, best);
     }
     L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
 #ifdef RT_PROFILE_PHASES

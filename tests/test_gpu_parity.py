@@ -162,7 +162,8 @@ def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, ro
     assert outliers.mean() <= 0.02, f"{outliers.sum()} of {outliers.size} pixels differ (max {diff.max()})"
     # a path that diverges near the root takes its whole subtree (up to ~10^max_depth rays) with it
     assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
-    assert abs(float(img.mean()) - float(want.mean())) <= 2e-3 * float(want.mean())
+    # exact: only libm-ulp divergences; fused: a few pixels follow another path (other samples of the same estimator)
+    assert abs(float(img.mean()) - float(want.mean())) <= (2e-3 if exact else 1e-2) * float(want.mean())
 
 
 @pytest.mark.parametrize("scene", ["demo_path", "csg_example"])
