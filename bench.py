@@ -10,7 +10,7 @@ roulette=3, max-depth=5, on the synthetic N-random-sphere + floor + sky scene of
 Default N = 512: 3.1e10 rays per frame (927 per sample), about 7 s on one MI355X.  The 4096-sphere scene of
 BASELINE configs[4] is the same generator with --spheres 4096; its 1080p frame is 3.9e11 rays x 4098 sphere
 tests = 1.6e15 tests, minutes per frame on one GPU, so it is run explicitly (DESIGN.md has the numbers).
-With N ranks the frame's rows are dealt in 16-row cyclic bands (strong scaling: the frame is fixed), each rank
+With N ranks the frame's rows are dealt round-robin row by row (strong scaling: the frame is fixed), each rank
 renders its bands into HBM and rank 0 gathers them over RCCL.  The scene and the framebuffers are resident in
 HBM before the timed region.  A ray = one World::ray_intersection query (closest hit over every object).
 
@@ -229,7 +229,7 @@ def main():
                                    f"max-depth={args.max_depth}, seq-number=54",
                        "objects": scene.count("n_objects"), "samples_per_frame": samples_total, "rays_per_frame": rays_total,
                        "rays_per_sample": rays_total / max(samples_total, 1),
-                       "parallelism": f"row-bands16x{world_size}" if world_size > 1 else "single"},
+                       "parallelism": f"rows-cyclic-x{world_size}" if world_size > 1 else "single"},
             "kernel_ms_per_step_max_rank": kernel_ms_max,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": pmc_traffic(args),

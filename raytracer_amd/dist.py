@@ -4,7 +4,9 @@ The path shards by pixel rows with no exchange while rendering (every pixel samp
 random stream depends only on its global index), so the only collective is one gather of the finished
 bands: each rank sends its compact [n_local_rows, W, 3] buffer to rank 0 over RCCL
 (`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests), rank 0 scatters the rows into the
-row-major HdrImage layout.  Bands are 16 rows dealt round-robin, because path-mode cost is strongly row
+row-major HdrImage layout.  Rows are dealt round-robin one by one (BAND_ROWS = 1): neighbouring rows cost alike, so every
+rank gets the same mix (1080 rows over 8 ranks: 135 each; 16-row bands would give 9 bands to some ranks and 8 to
+others, 6 % apart before the content is even looked at), because path-mode cost is strongly row
 dependent (sky rows cost ~1 ray per sample, object rows hundreds).
 """
 from __future__ import annotations
@@ -14,7 +16,7 @@ import torch.distributed as dist
 
 from .tracer import RowBands
 
-BAND_ROWS = 16
+BAND_ROWS = 1
 
 
 def rank_rows(height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> RowBands:

@@ -50,7 +50,8 @@ class RowBands:
 
     @staticmethod
     def cyclic(height: int, rank: int, world: int, band_rows: int = 16) -> "RowBands":
-        """16-row bands dealt round-robin to ranks: path cost is strongly row dependent."""
+        """Bands of band_rows rows dealt round-robin to ranks: path cost is strongly row dependent.
+        raytracer_amd.dist uses band_rows = 1."""
         n = sum(min(band_rows, height - start) for start in range(rank * band_rows, height, world * band_rows))
         return RowBands(band_rows, band_rows * world, band_rows * rank, n)
 

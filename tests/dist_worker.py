@@ -1,6 +1,6 @@
 """One rank of the world_size-N CPU rehearsal of the sharded frame (tests/test_dist_gloo.py launches it).
 
-Same host logic as bench.py's N>1 path — rank_rows -> render this rank's cyclic 16-row bands -> gather_rows to
+Same host logic as bench.py's N>1 path — rank_rows -> render this rank's cyclic rows -> gather_rows to
 rank 0 — with the `gloo` backend and the CPU oracle standing in for the device renderer (it takes the same
 rt_render_cfg band fields as rt_render).  Rank 0 saves the assembled image.
 """
