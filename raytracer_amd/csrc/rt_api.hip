@@ -283,6 +283,35 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       cb.tops.back().leaf_end = static_cast<int32_t>(cb.leaves.size());
     }
   }
+  // world <-> local transforms of every shape with its CSG ancestors folded in (computed in binary64, rounded once)
+  std::vector<float> shape_w2l(d->shape_inv, d->shape_inv + 12 * static_cast<size_t>(d->n_shapes));
+  std::vector<float> shape_l2w(d->shape_fwd, d->shape_fwd + 12 * static_cast<size_t>(d->n_shapes));
+  {
+    struct Aff { double m[12]; };
+    auto load = [](const float *f) { Aff a; for (int i = 0; i < 12; ++i) a.m[i] = f[i]; return a; };
+    auto mul = [](const Aff &a, const Aff &b) { // x -> a(b(x))
+      Aff r;
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+          r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+        r.m[9 + i] = a.m[3 * i] * b.m[9] + a.m[3 * i + 1] * b.m[10] + a.m[3 * i + 2] * b.m[11] + a.m[9 + i];
+      }
+      return r;
+    };
+    for (const rtd::CsgLeaf &leaf : cb.leaves) {
+      Aff w2l = load(d->shape_inv + 12 * static_cast<size_t>(leaf.shape)); // applied last
+      Aff l2w = load(d->shape_fwd + 12 * static_cast<size_t>(leaf.shape)); // applied first
+      for (int k = leaf.path_len - 1; k >= 0; --k) {                       // parent ... root
+        const int32_t node = cb.path[leaf.path_begin + k].node;
+        w2l = mul(w2l, load(d->csg_inv + 12 * static_cast<size_t>(node)));
+        l2w = mul(load(d->csg_fwd + 12 * static_cast<size_t>(node)), l2w);
+      }
+      for (int i = 0; i < 12; ++i) {
+        shape_w2l[12 * static_cast<size_t>(leaf.shape) + i] = static_cast<float>(w2l.m[i]);
+        shape_l2w[12 * static_cast<size_t>(leaf.shape) + i] = static_cast<float>(l2w.m[i]);
+      }
+    }
+  }
   // translation * uniform scaling spheres can be tested in world space from (centre, r^2)
   std::vector<float> sphere_iso(spheres.size() * 4);
   bool all_iso = !spheres.empty();
@@ -342,6 +371,8 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.n_objects = static_cast<int32_t>(d->n_objects);
   UP(upload(sc, d->shape_fwd, 12 * static_cast<size_t>(d->n_shapes), &S.shape_fwd));
   UP(upload(sc, d->shape_inv, 12 * static_cast<size_t>(d->n_shapes), &S.shape_inv));
+  UP(upload(sc, shape_w2l, &S.shape_w2l));
+  UP(upload(sc, shape_l2w, &S.shape_l2w));
   UP(upload(sc, d->shape_kind, d->n_shapes, &S.shape_kind));
   UP(upload(sc, d->shape_material, d->n_shapes, &S.shape_material));
   UP(upload(sc, cb.leaves, &S.csg_leaf));

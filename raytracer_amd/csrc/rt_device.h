@@ -364,6 +364,96 @@ RT_DEV bool csg_ray_intersection(const Scene &s, const CsgTop &top, const Ray &r
   return found;
 }
 
+// The same evaluation for the FMA path kernels: every leaf is reached from world space with ONE composed
+// transform (Scene::shape_w2l), candidate hits are tested for "inside the sibling subtree" at their world point, and
+// the winner's record is built once at the end.  Same hits, same tie rules; rounding differs (statistical bar).
+RT_DEV bool shape_is_point_inside_fast(const Scene &s, int shape, V3 pw) {
+  const float *m = s.shape_w2l + 12 * shape;
+  if (s.shape_kind[shape] == RT_SHAPE_SPHERE) {
+    const V3 q = hom_point_fast(m, pw);
+    return fmaf(q.x, q.x, fmaf(q.y, q.y, q.z * q.z)) < 1.f;
+  }
+  return fmaf(m[6], pw.x, fmaf(m[7], pw.y, fmaf(m[8], pw.z, m[11]))) < 0.f;
+}
+
+RT_DEV bool csg_prog_inside_fast(const Scene &s, int begin, int end, V3 pw) {
+  uint32_t bits = 0; // boolean stack, top = bit 0
+  for (int e = begin; e < end; ++e) {
+    const CsgProgEntry pe = s.csg_prog[e];
+    if (!pe.is_op) {
+      bits = (bits << 1) | (shape_is_point_inside_fast(s, pe.arg, pw) ? 1u : 0u);
+    } else {
+      const bool in2 = bits & 1u, in1 = (bits >> 1) & 1u;
+      bool r;
+      switch (pe.arg) {
+      case RT_CSG_UNION: r = in1 || in2; break;
+      case RT_CSG_INTERSECTION: r = in1 && in2; break;
+      case RT_CSG_DIFFERENCE: r = in1 && !in2; break;
+      default: r = in1 || in2; break; // FUSION
+      }
+      bits = ((bits >> 2) << 1) | (r ? 1u : 0u);
+    }
+  }
+  return bits & 1u;
+}
+
+RT_DEV bool csg_ray_intersection_fast(const Scene &s, const CsgTop &top, const Ray &ray_world, Hit &best) {
+  bool found = false;
+  float best_t = 0.f;
+  int best_shape = -1;
+  for (int li = top.leaf_begin; li < top.leaf_end; ++li) {
+    const CsgLeaf leaf = s.csg_leaf[li];
+    const float *inv = s.shape_w2l + 12 * leaf.shape;
+    Ray ray = ray_world;
+    ray.o = hom_point_fast(inv, ray_world.o);
+    ray.d = hom_vec_fast(inv, ray_world.d);
+    float ts[2];
+    int nt;
+    const bool sphere = s.shape_kind[leaf.shape] == RT_SHAPE_SPHERE;
+    if (sphere)
+      nt = solve_ray_sphere(ray, ts[0], ts[1]);
+    else
+      nt = solve_ray_plane(ray, ts[0]) ? 1 : 0;
+    bool first_of_leaf = true;
+    for (int i = 0; i < nt; ++i) {
+      const float t = ts[i];
+      if (sphere && !(t > ray.tmin && t < ray.tmax))
+        continue;
+      const bool better = !found || (first_of_leaf ? (t <= best_t) : (t < best_t));
+      if (!better) { // cannot win: skip the inside tests (the exact evaluator tests validity first; same outcome)
+        continue;
+      }
+      const V3 pw = mk3(fmaf(t, ray_world.d.x, ray_world.o.x), fmaf(t, ray_world.d.y, ray_world.o.y), fmaf(t, ray_world.d.z, ray_world.o.z));
+      bool valid = true;
+      for (int k = leaf.path_len - 1; k >= 0 && valid; --k) {
+        const CsgStep st = s.csg_path[leaf.path_begin + k];
+        const int *range = s.csg_prog_range + 4 * st.node + 2 * (1 - st.side);
+        valid = csg_hit_valid(s.csg_op[st.node], st.side, csg_prog_inside_fast(s, range[0], range[1], pw));
+      }
+      if (!valid)
+        continue;
+      found = true;
+      best_t = t;
+      best_shape = leaf.shape;
+      first_of_leaf = false;
+    }
+  }
+  if (found) {
+    const float *inv = s.shape_w2l + 12 * best_shape;
+    const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+    const V3 p = mk3(fmaf(best_t, d.x, o.x), fmaf(best_t, d.y, o.y), fmaf(best_t, d.z, o.z));
+    V3 n = (s.shape_kind[best_shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
+    n = scale3(n, copysignf(1.0f, -fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z))));
+    best.t = best_t;
+    best.shape = best_shape;
+    best.object = top.object;
+    best.local = p;
+    best.point = hom_point_fast(s.shape_l2w + 12 * best_shape, p);
+    best.normal = hom_transposed_fast(inv, n);
+  }
+  return found;
+}
+
 // ---------------------------------------------------------------------------------------------
 // World — include/shapes.hpp:520-604
 // ---------------------------------------------------------------------------------------------
@@ -495,7 +585,8 @@ template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray,
   for (int i = 0; i < s.n_csg_tops; ++i) {
     const CsgTop top = s.csg_tops[i];
     Hit c;
-    if (csg_ray_intersection(s, top, ray, c) && (c.t < best.t || (c.t == best.t && c.object < best.object))) {
+    const bool csg_hit = FAST ? csg_ray_intersection_fast(s, top, ray, c) : csg_ray_intersection(s, top, ray, c);
+    if (csg_hit && (c.t < best.t || (c.t == best.t && c.object < best.object))) {
       best.t = c.t;
       best.object = c.object;
       h = c;

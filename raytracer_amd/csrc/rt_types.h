@@ -62,6 +62,10 @@ struct Scene {
   const float *shape_inv;         // [n_shapes][12]
   const uint8_t *shape_kind;
   const uint32_t *shape_material;
+  // world <-> shape-local transforms with the CSG ancestors' transforms folded in (== shape_inv / shape_fwd for a
+  // top-level shape): what the FMA path kernels use instead of walking the chain of nodes
+  const float *shape_w2l;         // [n_shapes][12]
+  const float *shape_l2w;         // [n_shapes][12]
   // CSG tables
   const CsgLeaf *csg_leaf;
   const CsgStep *csg_path;
