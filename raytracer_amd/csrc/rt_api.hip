@@ -330,6 +330,17 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
                   d->pigment_kind[d->material_emission_pigment[m]] != RT_PIGMENT_UNIFORM;
 
+  std::vector<rtd::ShadeRec> shade(d->n_shapes);
+  for (uint32_t i = 0; i < d->n_shapes; ++i) {
+    const uint32_t m = d->shape_material[i], pb = d->material_brdf_pigment[m], pe = d->material_emission_pigment[m];
+    rtd::ShadeRec &r = shade[i];
+    std::memcpy(r.brdf_color, d->pigment_color1 + 3 * static_cast<size_t>(pb), sizeof r.brdf_color);
+    std::memcpy(r.emit_color, d->pigment_color1 + 3 * static_cast<size_t>(pe), sizeof r.emit_color);
+    r.material = m;
+    r.flags = (d->material_brdf[m] == RT_BRDF_SPECULAR ? 1u : 0u) | (d->pigment_kind[pb] == RT_PIGMENT_UNIFORM ? 2u : 0u) |
+              (d->pigment_kind[pe] == RT_PIGMENT_UNIFORM ? 4u : 0u);
+  }
+
   // -- device ------------------------------------------------------------------------------------
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
@@ -375,6 +386,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, shape_l2w, &S.shape_l2w));
   UP(upload(sc, d->shape_kind, d->n_shapes, &S.shape_kind));
   UP(upload(sc, d->shape_material, d->n_shapes, &S.shape_material));
+  UP(upload(sc, shade, &S.shape_shade));
   UP(upload(sc, cb.leaves, &S.csg_leaf));
   UP(upload(sc, cb.path, &S.csg_path));
   UP(upload(sc, d->csg_fwd, 12 * static_cast<size_t>(d->n_csg_nodes), &S.csg_fwd));
@@ -470,12 +482,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   }
 
   constexpr int BLOCK = 256;
-  static_assert(BLOCK == rtd::PATH_THREADS, "k_render_path is launched with PATH_THREADS lanes");
   unsigned grid, block = BLOCK;
   const void *path_kernel = nullptr;
   if (cfg->mode == RT_MODE_PATH) {
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
+    block = rtd::PATH_THREADS;
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
     if (!exact && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan

@@ -90,6 +90,7 @@ template <int T> struct PathShared { // LDS state of one workgroup
   int pending[T];               // per sample slot: rays not yet shaded (-1: slot free)
   int owner[T];                 // per dealt child: node holder lane | child index << 16
   short free_list[T];
+  unsigned short rem[8 * T];    // children left per stack node, when the stack holds at most 8 T nodes (else node word 12)
   int wave_tot[T / 64];
   int n_free, n_pop, n_new;
   int res_count, exhausted;
@@ -170,6 +171,17 @@ template <int T, bool FAST> struct PathBlock {
   }
 
   RT_DEV float &node_word(int word, int node) const { return pool[(size_t)word * cap + node]; }
+  // children left of a stack node: in LDS when the whole stack's counters fit there (saves a dependent trip to HBM
+  // at the head of every iteration), else word 12 of the node
+  RT_DEV int get_rem(const PathShared<T> &sh, int node) const {
+    return cap <= 8 * T ? (int)sh.rem[node] : __float_as_int(node_word(12, node));
+  }
+  RT_DEV void set_rem(PathShared<T> &sh, int node, int v) const {
+    if (cap <= 8 * T)
+      sh.rem[node] = (unsigned short)v;
+    else
+      node_word(12, node) = __int_as_float(v);
+  }
 
   // Deals the children on top of the node stack, then fresh samples, to the lanes.  Returns false when
   // the workgroup has nothing left to do (uniform).
@@ -178,7 +190,7 @@ template <int T, bool FAST> struct PathBlock {
     const int nfree0 = sh.n_free;
     int rem = 0;
     if (tid < top)
-      rem = __float_as_int(node_word(12, top - 1 - tid));
+      rem = get_rem(sh, top - 1 - tid);
     int total;
     const int incl = block_scan_inclusive<T>(rem, sh.wave_tot, total);
     const int take = min(total, T);
@@ -188,7 +200,7 @@ template <int T, bool FAST> struct PathBlock {
       for (int c = lo; c < hi; ++c)
         sh.owner[c] = tid | ((first_child + (c - lo)) << 16);
       if (incl > T && lo < T)
-        node_word(12, top - 1 - tid) = __int_as_float(incl - T); // partly used: stays on the stack
+        set_rem(sh, top - 1 - tid, incl - T); // partly used: stays on the stack
     }
     const unsigned long long used_up = __ballot(rem > 0 && incl <= T);
     if ((tid & 63) == 0 && used_up)
@@ -275,11 +287,20 @@ template <int T, bool FAST> struct PathBlock {
       if (h.object < 0) {
         emitted = mk3(p.background[0], p.background[1], p.background[2]);
       } else {
-        const uint32_t m = s.shape_material[h.shape];
-        float u, v;
-        hit_uv(s, h, m, u, v);
-        V3 reflected = pigment_eval(s, s.material_brdf_pigment[m], u, v);
-        emitted = pigment_eval(s, s.material_emission_pigment[m], u, v);
+        const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + h.shape);
+        const float4 r0 = rec[0], r1 = rec[1];
+        const uint32_t mflags = __float_as_uint(r0.w);
+        V3 reflected = mk3(r0.x, r0.y, r0.z);
+        emitted = mk3(r1.x, r1.y, r1.z);
+        if ((mflags & 6u) != 6u) { // a pigment that reads (u, v): the general route
+          const uint32_t m = __float_as_uint(r1.w);
+          float u, v;
+          hit_uv(s, h, m, u, v);
+          if (!(mflags & 2u))
+            reflected = pigment_eval(s, s.material_brdf_pigment[m], u, v);
+          if (!(mflags & 4u))
+            emitted = pigment_eval(s, s.material_emission_pigment[m], u, v);
+        }
         const float hit_lum = fmaxf(fmaxf(reflected.x, reflected.y), reflected.z);
         push = hit_lum > 0.f;
         if (depth > p.roulette) {
@@ -291,7 +312,7 @@ template <int T, bool FAST> struct PathBlock {
         }
         push = push && depth < p.max_depth; // children deeper than max_depth are BLACK (renderers.hpp:210)
         if (push) {
-          brdf = s.material_brdf[m];
+          brdf = (int)(mflags & 1u);
           if (FAST)
             vec = (brdf == RT_BRDF_SPECULAR) ? specular_scatter_dir_fast(ray.d, h.normal) : normalized3_fast(h.normal);
           else
@@ -341,7 +362,7 @@ template <int T, bool FAST> struct PathBlock {
       node_word(9, node) = __uint_as_float((uint32_t)pcg.state);
       node_word(10, node) = __uint_as_float((uint32_t)(pcg.state >> 32));
       node_word(11, node) = __uint_as_float((uint32_t)slot | ((uint32_t)(depth + 1) << 16) | ((uint32_t)brdf << 31));
-      node_word(12, node) = __int_as_float(p.n_rays);
+      set_rem(sh, node, p.n_rays);
     }
     top += n_push;
     __syncthreads(); // accumulators, pending counts and node words are in place

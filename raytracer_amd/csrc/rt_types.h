@@ -46,6 +46,13 @@ struct CsgProgEntry {  // RPN program "is point inside this subtree?"
   int32_t path_len;
 };
 
+struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit shape's material in ONE load round trip
+  float brdf_color[3];   // colour of the BRDF pigment when it is uniform
+  uint32_t flags;        // bit 0: SpecularBRDF, bit 1: BRDF pigment is uniform, bit 2: emission pigment is uniform
+  float emit_color[3];
+  uint32_t material;
+};
+
 struct Scene {
   // scan lists
   const ScanRec *spheres; int32_t n_spheres;
@@ -62,6 +69,7 @@ struct Scene {
   const float *shape_inv;         // [n_shapes][12]
   const uint8_t *shape_kind;
   const uint32_t *shape_material;
+  const ShadeRec *shape_shade;
   // world <-> shape-local transforms with the CSG ancestors' transforms folded in (== shape_inv / shape_fwd for a
   // top-level shape): what the FMA path kernels use instead of walking the chain of nodes
   const float *shape_w2l;         // [n_shapes][12]
