@@ -1,0 +1,145 @@
+"""Edge cases of the hot path, GPU against the oracle through the C-ABI: empty and tiny worlds and images, extreme
+sampling settings, worlds made only of CSG, limits that must be refused with a message."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd import abi
+from raytracer_amd.scene import Camera, SceneBuilder, Transformation, compose, scaling, translation
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from raytracer_amd import tracer
+    return tracer
+
+
+def camera():
+    return Camera(abi.RT_CAMERA_PERSPECTIVE, compose(translation([-3, 0, 0.2])), None, 1.0)
+
+
+def small_world(n_spheres=3, csg_only=False, lights=True):
+    b = SceneBuilder()
+    sky = b.material("diffuse", b.pigment_uniform((0, 0, 0)), b.pigment_uniform((0.4, 0.5, 0.9)))
+    red = b.material("diffuse", b.pigment_uniform((0.8, 0.2, 0.1)))
+    mirror = b.material("specular", b.pigment_uniform((0.6, 0.6, 0.6)))
+    check = b.material("diffuse", b.pigment_checkered((0.9, 0.9, 0.2), (0.1, 0.1, 0.4), 3))
+    if csg_only:
+        a = b.sphere(compose(scaling([30, 30, 30])), sky, norender=True)
+        c = b.sphere(compose(translation([0, 0, 0]), scaling([0.9, 0.9, 0.9])), red, norender=True)
+        d = b.sphere(compose(translation([0.6, 0.3, 0.2])), mirror, norender=True)
+        b.csg(a, b.plane(compose(translation([0, 0, 40])), sky, norender=True), "intersection")   # the sky, as a CSG object
+        b.csg(c, d, "difference")
+    else:
+        b.plane(compose(translation([0, 0, -1])), check)
+        b.sphere(compose(scaling([30, 30, 30])), sky)
+        for k in range(n_spheres):
+            b.sphere(compose(translation([0.4 * k, -1.0 + 0.9 * k, -0.3 + 0.2 * k]), scaling([0.5, 0.5, 0.5])), red if k % 2 else mirror)
+    if lights:
+        b.point_light((-2, 2, 3), (1, 1, 1), 0.0)
+    b.camera = camera()
+    return b.build()
+
+
+def both(gpu, scene, w, h, aa, mode, **kw):
+    world = gpu.DeviceWorld(scene)
+    t = gpu.GpuImageTracer(w, h, scene.camera, aa)
+    img = t.fire_all_rays(world, gpu.RenderMode(mode, **kw))
+    stats = t.last_stats
+    world.close()
+    okw = {k: v for k, v in kw.items() if k != "exact"}
+    want, ostats = O.render(scene, O.make_cfg(w, h, mode, spp_edge=aa, **okw))
+    return img, stats, want, ostats
+
+
+@pytest.mark.parametrize("mode", ["onoff", "flat", "pointlight", "path"])
+def test_empty_world_renders_the_background(gpu, mode):
+    b = SceneBuilder()
+    b.camera = camera()
+    scene = b.build()
+    img, stats, want, _ = both(gpu, scene, 7, 5, 2, mode, background=(0.25, 0.5, 0.75))
+    assert np.array_equal(img, want)
+    assert np.allclose(img, 0.0 if mode == "onoff" else (0.25, 0.5, 0.75))
+    assert stats.samples == 7 * 5 * 4
+
+
+@pytest.mark.parametrize("w,h,aa", [(1, 1, 1), (1, 1, 9), (1, 17, 2), (23, 1, 3), (3, 2, 16)])
+@pytest.mark.parametrize("mode", ["flat", "pointlight"])
+def test_tiny_and_odd_images_deterministic_modes(gpu, mode, w, h, aa):
+    img, stats, want, ostats = both(gpu, small_world(), w, h, aa, mode)
+    assert np.array_equal(img, want) and stats.rays == ostats.rays and stats.samples == w * h * aa * aa
+
+
+@pytest.mark.parametrize("kw", [dict(n_rays=1, roulette=0, max_depth=0), dict(n_rays=1, roulette=1, max_depth=64),
+                                dict(n_rays=25, roulette=0, max_depth=1), dict(n_rays=2, roulette=100, max_depth=9),
+                                dict(n_rays=7, roulette=2, max_depth=3, seq_number=2**63 + 12345)])
+def test_path_extreme_settings_exact_kernel_follows_the_oracle(gpu, kw):
+    img, stats, want, ostats = both(gpu, small_world(), 20, 12, 1, "path", exact=True, **kw)
+    diff = np.abs(img - want).max(axis=-1)
+    assert (diff > 1e-4).mean() <= 0.03, (diff > 1e-4).sum()
+    assert abs(int(stats.rays) - int(ostats.rays)) <= 0.05 * ostats.rays
+    img2, *_ = both(gpu, small_world(), 20, 12, 1, "path", **kw)          # and the fused kernel: same estimator
+    assert abs(float(img2.mean()) - float(want.mean())) <= 0.05 * float(want.mean())
+
+
+@pytest.mark.parametrize("mode", ["onoff", "flat", "pointlight"])
+def test_world_made_only_of_csg_objects(gpu, mode):
+    img, stats, want, ostats = both(gpu, small_world(csg_only=True), 48, 32, 2, mode)
+    assert np.array_equal(img, want) and stats.rays == ostats.rays
+
+
+def test_world_made_only_of_csg_objects_path(gpu):
+    img, stats, want, ostats = both(gpu, small_world(csg_only=True), 32, 24, 2, "path", n_rays=3, max_depth=3, exact=True)
+    assert (np.abs(img - want).max(axis=-1) > 1e-4).mean() <= 0.02
+    fast, *_ = both(gpu, small_world(csg_only=True), 32, 24, 2, "path", n_rays=3, max_depth=3)
+    assert (np.abs(fast - want).max(axis=-1) > 1e-4).mean() <= 0.05
+
+
+def test_pointlight_without_lights_and_with_many(gpu):
+    img, _, want, _ = both(gpu, small_world(lights=False), 24, 16, 1, "pointlight")
+    assert np.array_equal(img, want)
+    b_scene = small_world()
+    # 40 lights: add to the flat arrays directly
+    rng = np.random.default_rng(1)
+    b_scene.light_point = np.ascontiguousarray(rng.uniform(-4, 4, 120).astype(np.float32))
+    b_scene.light_color = np.ascontiguousarray(rng.uniform(0, 1, 120).astype(np.float32))
+    b_scene.light_radius = np.ascontiguousarray(rng.uniform(0, 2, 40).astype(np.float32))
+    img, stats, want, ostats = both(gpu, b_scene, 24, 16, 1, "pointlight")
+    assert np.array_equal(img, want) and stats.rays == ostats.rays
+
+
+def test_limits_are_refused_with_a_message(gpu):
+    from raytracer_amd.lib import RtError
+    scene = small_world()
+    world = gpu.DeviceWorld(scene)
+    t = gpu.GpuImageTracer(8, 8, scene.camera, 1)
+    for kw in (dict(n_rays=65536), dict(n_rays=2, max_depth=65), dict(n_rays=0), dict(max_depth=-1)):
+        with pytest.raises(RtError) as e:
+            t.fire_all_rays(world, gpu.RenderMode("path", **kw))
+        assert str(e.value)
+    with pytest.raises(RtError):
+        t.fire_all_rays(world, gpu.RenderMode("pointlight", max_mirror_bounces=0))
+    world.close()
+    # CSG deeper than RT_MAX_CSG_DEPTH
+    b = SceneBuilder()
+    m = b.material("diffuse", b.pigment_uniform((1, 1, 1)))
+    ref = b.sphere(Transformation(), m, norender=True)
+    for _ in range(abi.RT_MAX_CSG_DEPTH + 1):
+        ref = b.csg(ref, b.sphere(Transformation(), m, norender=True), "union", norender=True)
+    b._a["objects"].append(ref)
+    b.camera = camera()
+    with pytest.raises(RtError):
+        gpu.DeviceWorld(b.build())
+
+
+def test_two_worlds_and_repeated_renders_do_not_interfere(gpu):
+    a, b = small_world(2), small_world(5)
+    wa, wb = gpu.DeviceWorld(a), gpu.DeviceWorld(b)
+    ta, tb = gpu.GpuImageTracer(40, 30, a.camera, 2), gpu.GpuImageTracer(33, 21, b.camera, 1)
+    mode = gpu.RenderMode("path", n_rays=3, max_depth=3)
+    ia1, ib1 = ta.fire_all_rays(wa, mode), tb.fire_all_rays(wb, mode)
+    ib2, ia2 = tb.fire_all_rays(wb, mode), ta.fire_all_rays(wa, mode)
+    wa.close(), wb.close()
+    assert np.array_equal(ia1, ia2) and np.array_equal(ib1, ib2)
