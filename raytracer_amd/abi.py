@@ -20,6 +20,7 @@ RT_MODE_ONOFF, RT_MODE_FLAT, RT_MODE_POINTLIGHT, RT_MODE_PATH = 0, 1, 2, 3
 RT_RNG_PER_NODE_STREAMS, RT_RNG_SERIAL_REFERENCE = 0, 1
 RT_FLAG_EXACT_ARITHMETIC = 1
 RT_FLAG_OBJECT_SPACE_SPHERES = 2
+RT_FLAG_ACCEL_BVH = 4
 RT_MAX_CSG_DEPTH = 8
 RT_MAX_CSG_LEAVES = 32
 

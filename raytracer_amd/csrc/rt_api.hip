@@ -79,6 +79,57 @@ rt_status ensure(DeviceBuffer &b, size_t bytes) {
 
 // ---- validation + CSG preprocessing ---------------------------------------------------------------
 
+// Bounding-volume hierarchy over the top-level spheres: median split of the centroids along the widest axis, leaves of
+// at most 4, nodes in depth-first order (left child = next node).  The box of a sphere under the affine map M is its
+// centre +- the row norms of M's linear part; boxes are padded so that rounding in the slab test cannot lose a hit.
+struct BvhBuild {
+  std::vector<rtd::BvhNode> nodes;
+  std::vector<int32_t> order;
+  std::vector<float> lo, hi, centre; // per sphere, 3 each
+
+  void bounds(int first, int count, float *blo, float *bhi) const {
+    for (int c = 0; c < 3; ++c)
+      blo[c] = INFINITY, bhi[c] = -INFINITY;
+    for (int k = first; k < first + count; ++k)
+      for (int c = 0; c < 3; ++c) {
+        blo[c] = std::min(blo[c], lo[3 * order[k] + c]);
+        bhi[c] = std::max(bhi[c], hi[3 * order[k] + c]);
+      }
+  }
+
+  int build(int first, int count) {
+    const int me = static_cast<int>(nodes.size());
+    nodes.emplace_back();
+    float blo[3], bhi[3];
+    bounds(first, count, blo, bhi);
+    std::memcpy(nodes[me].lo, blo, sizeof blo);
+    std::memcpy(nodes[me].hi, bhi, sizeof bhi);
+    if (count <= 4) {
+      nodes[me].a = first;
+      nodes[me].b = -count;
+      return me;
+    }
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = first; k < first + count; ++k)
+      for (int c = 0; c < 3; ++c) {
+        clo[c] = std::min(clo[c], centre[3 * order[k] + c]);
+        chi[c] = std::max(chi[c], centre[3 * order[k] + c]);
+      }
+    int axis = 0;
+    for (int c = 1; c < 3; ++c)
+      if (chi[c] - clo[c] > chi[axis] - clo[axis])
+        axis = c;
+    const int half = count / 2;
+    std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
+                     [&](int32_t x, int32_t y) { return centre[3 * x + axis] < centre[3 * y + axis]; });
+    build(first, half); // == me + 1
+    const int right = build(first + half, count - half);
+    nodes[me].a = 0;
+    nodes[me].b = right | (axis << 28);
+    return me;
+  }
+};
+
 struct CsgBuild {
   const rt_scene_desc *d;
   std::vector<rtd::CsgTop> tops;
@@ -325,6 +376,24 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     sphere_iso[4 * i + 0] = fwd[9], sphere_iso[4 * i + 1] = fwd[10], sphere_iso[4 * i + 2] = fwd[11];
     sphere_iso[4 * i + 3] = fwd[0] * fwd[0];
   }
+  BvhBuild bvh;
+  if (spheres.size() >= 2) {
+    const size_t n = spheres.size();
+    bvh.lo.resize(3 * n), bvh.hi.resize(3 * n), bvh.centre.resize(3 * n), bvh.order.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      const float *fwd = d->shape_fwd + 12 * static_cast<size_t>(spheres[i].shape);
+      bvh.order[i] = static_cast<int32_t>(i);
+      for (int c = 0; c < 3; ++c) {
+        const double half = std::sqrt(double(fwd[3 * c]) * fwd[3 * c] + double(fwd[3 * c + 1]) * fwd[3 * c + 1] +
+                                      double(fwd[3 * c + 2]) * fwd[3 * c + 2]);
+        const double pad = half * 1e-4 + std::fabs(double(fwd[9 + c])) * 1e-6 + 1e-6;
+        bvh.centre[3 * i + c] = fwd[9 + c];
+        bvh.lo[3 * i + c] = static_cast<float>(fwd[9 + c] - half - pad);
+        bvh.hi[3 * i + c] = static_cast<float>(fwd[9 + c] + half + pad);
+      }
+    }
+    bvh.build(0, static_cast<int>(n));
+  }
   std::vector<uint8_t> needs_uv(d->n_materials);
   for (uint32_t m = 0; m < d->n_materials; ++m)
     needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
@@ -369,6 +438,9 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, spheres, &S.spheres));
   UP(upload(sc, sphere_iso, &S.sphere_iso));
   S.spheres_all_iso = all_iso ? 1 : 0;
+  UP(upload(sc, bvh.nodes, &S.bvh));
+  S.n_bvh_nodes = static_cast<int32_t>(bvh.nodes.size());
+  UP(upload(sc, bvh.order, &S.bvh_order));
   UP(upload(sc, planes, &S.planes));
   UP(upload(sc, cb.tops, &S.csg_tops));
   S.n_spheres = static_cast<int32_t>(spheres.size());
@@ -488,9 +560,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
     block = rtd::PATH_THREADS;
+    const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
+    if (use_bvh)
+      path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false, true>)
+                          : reinterpret_cast<const void *>(rtd::k_render_path<true, true>);
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
-    if (!exact && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
+    if (!exact && !use_bvh && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
       const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.

@@ -46,6 +46,13 @@ struct CsgProgEntry {  // RPN program "is point inside this subtree?"
   int32_t path_len;
 };
 
+struct BvhNode {       // 32 B: bounding-volume hierarchy over the top-level spheres (optional mode, RT_FLAG_ACCEL_BVH)
+  float lo[3];
+  int32_t a;           // leaf: first entry in bvh_order[]; inner: unused (the left child is the next node)
+  float hi[3];
+  int32_t b;           // leaf: -(number of spheres); inner: right child index | split axis << 28
+};
+
 struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit shape's material in ONE load round trip
   float brdf_color[3];   // colour of the BRDF pigment when it is uniform
   uint32_t flags;        // bit 0: SpecularBRDF, bit 1: BRDF pigment is uniform, bit 2: emission pigment is uniform
@@ -61,6 +68,8 @@ struct Scene {
   int32_t wide_first, wide_rows;
   const float *sphere_iso;        // [n_spheres][4] world centre + r^2, valid iff spheres_all_iso
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
+  const BvhNode *bvh; int32_t n_bvh_nodes;   // depth-first order, node 0 = root; 0 nodes: no hierarchy
+  const int32_t *bvh_order;       // positions in spheres[] grouped by leaf
   const ScanRec *planes;  int32_t n_planes;
   const CsgTop *csg_tops; int32_t n_csg_tops;
   int32_t n_objects;

@@ -34,6 +34,7 @@ class RenderMode:
     max_mirror_bounces: int = 64                 # the reference has no cap (renderers.hpp:129-152)
     exact: bool = False                          # path mode: unfused reference-order arithmetic in the scan
     object_space_spheres: bool = False           # path mode, large worlds: never use the world-space sphere form
+    bvh: bool = False                            # path mode: closest sphere through a BVH instead of the linear scan
 
 
 @dataclass
@@ -148,7 +149,8 @@ class GpuImageTracer:
         cfg.band_rows, cfg.band_stride, cfg.band_offset = rows.band_rows, rows.band_stride, rows.band_offset
         cfg.n_local_rows = rows.n_local_rows
         cfg.flags = (abi.RT_FLAG_EXACT_ARITHMETIC if mode.exact else 0) | \
-            (abi.RT_FLAG_OBJECT_SPACE_SPHERES if mode.object_space_spheres else 0)
+            (abi.RT_FLAG_OBJECT_SPACE_SPHERES if mode.object_space_spheres else 0) | \
+            (abi.RT_FLAG_ACCEL_BVH if mode.bvh else 0)
         return cfg
 
     def fire_all_rays(self, world: DeviceWorld, mode: RenderMode, rows: RowBands | None = None, out=None,

@@ -293,3 +293,28 @@ def test_path_wide_kernel_row_bands_and_determinism():
         out[rows.image_rows()] = tr.fire_all_rays(world, RenderMode("path", **kw), rows)
     world.close()
     assert np.array_equal(out, whole)
+
+
+# ---- optional BVH mode (RT_FLAG_ACCEL_BVH): same hits as the linear scan, fewer tests ----
+
+@pytest.mark.parametrize("kind,n", [("iso", 70), ("iso", 600), ("general", 300), ("iso", 4000)])
+def test_bvh_mode_finds_the_linear_scan_winner(kind, n):
+    """With the unfused arithmetic every sphere test gives the same t through the hierarchy as in the linear scan and
+    candidates compare as (t, object index), so the two path renders must be IDENTICAL, ray count included."""
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(n)[0] if kind == "iso" else _ellipsoid_world(n)
+    world = DeviceWorld(scene)
+    kw = dict(n_rays=3, roulette=2, max_depth=3, seq_number=9)
+    tr = GpuImageTracer(48, 30, scene.camera, 2)
+    linear = tr.fire_all_rays(world, RenderMode("path", exact=True, **kw))
+    rays_linear = int(tr.last_stats.rays)
+    bvh = tr.fire_all_rays(world, RenderMode("path", exact=True, bvh=True, **kw))
+    rays_bvh = int(tr.last_stats.rays)
+    fast = tr.fire_all_rays(world, RenderMode("path", bvh=True, **kw))
+    world.close()
+    assert np.array_equal(bvh, linear) and rays_bvh == rays_linear
+    # the fused arithmetic leaves the unfused paths at some hit decisions (per SAMPLE: 2 % at n=600, 17 % at n=4000, see
+    # above; a pixel here is 4 samples); the estimator is the same
+    diff = np.abs(fast - linear).max(axis=-1)
+    assert (diff > 1e-4).mean() <= (0.25 if n < 2000 else 0.60)
+    assert abs(float(fast.mean()) - float(linear.mean())) <= 0.03 * float(linear.mean())
