@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -13,6 +14,7 @@
 
 #include "../../include/raytracer_amd.h"
 #include "rt_kernels.h"
+#include "rt_bvh.h"
 #include "rt_tonemap.h"
 
 namespace {
@@ -79,54 +81,111 @@ rt_status ensure(DeviceBuffer &b, size_t bytes) {
 
 // ---- validation + CSG preprocessing ---------------------------------------------------------------
 
-// Bounding-volume hierarchy over the top-level spheres: median split of the centroids along the widest axis, leaves of
-// at most 4, nodes in depth-first order (left child = next node).  The box of a sphere under the affine map M is its
-// centre +- the row norms of M's linear part; boxes are padded so that rounding in the slab test cannot lose a hit.
+// Bounding-volume hierarchy over the top-level spheres (RT_FLAG_ACCEL_BVH, rt_bvh.h): median split of the centroids
+// along the widest axis down to leaves of at most 4, nodes in heap order (root = slot 1, children of n = 2n, 2n + 1).
+// The box of a sphere under the affine map M is its centre +- the row norms of M's linear part, padded so that rounding
+// in the slab test cannot lose a hit.  Spheres that would blow up every box above them (a sky sphere around the whole
+// scene) stay out of the tree and are scanned linearly.
 struct BvhBuild {
-  std::vector<rtd::BvhNode> nodes;
-  std::vector<int32_t> order;
+  static constexpr int LEAF_MAX = rtd::BVH_LEAF_MAX;
+  std::vector<int32_t> order;        // sphere positions: [0, n_small) grouped by leaf, then the big ones, ascending
   std::vector<float> lo, hi, centre; // per sphere, 3 each
+  std::vector<float> box;            // per heap slot: lo[3], hi[3] (before quantisation)
+  std::vector<uint32_t> leaf;        // per heap slot: 0 or count << 24 | first
+  std::vector<rtd::BvhNode> nodes;
+  float origin[3] = {0.f, 0.f, 0.f}, scale[3] = {1.f, 1.f, 1.f};
+  int n_small = 0;
 
-  void bounds(int first, int count, float *blo, float *bhi) const {
-    for (int c = 0; c < 3; ++c)
-      blo[c] = INFINITY, bhi[c] = -INFINITY;
+  void build(size_t slot, int first, int count) {
+    if (box.size() < 6 * (slot + 1))
+      box.resize(6 * (slot + 1), 0.f), leaf.resize(slot + 1, 0u);
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int k = first; k < first + count; ++k)
       for (int c = 0; c < 3; ++c) {
         blo[c] = std::min(blo[c], lo[3 * order[k] + c]);
         bhi[c] = std::max(bhi[c], hi[3 * order[k] + c]);
-      }
-  }
-
-  int build(int first, int count) {
-    const int me = static_cast<int>(nodes.size());
-    nodes.emplace_back();
-    float blo[3], bhi[3];
-    bounds(first, count, blo, bhi);
-    std::memcpy(nodes[me].lo, blo, sizeof blo);
-    std::memcpy(nodes[me].hi, bhi, sizeof bhi);
-    if (count <= 4) {
-      nodes[me].a = first;
-      nodes[me].b = -count;
-      return me;
-    }
-    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = first; k < first + count; ++k)
-      for (int c = 0; c < 3; ++c) {
         clo[c] = std::min(clo[c], centre[3 * order[k] + c]);
         chi[c] = std::max(chi[c], centre[3 * order[k] + c]);
       }
+    std::memcpy(&box[6 * slot], blo, sizeof blo);
+    std::memcpy(&box[6 * slot + 3], bhi, sizeof bhi);
+    if (count <= LEAF_MAX) {
+      leaf[slot] = (static_cast<uint32_t>(count) << 24) | static_cast<uint32_t>(first);
+      return;
+    }
     int axis = 0;
     for (int c = 1; c < 3; ++c)
       if (chi[c] - clo[c] > chi[axis] - clo[axis])
         axis = c;
-    const int half = count / 2;
+    const int half = (count + 1) / 2;
     std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
                      [&](int32_t x, int32_t y) { return centre[3 * x + axis] < centre[3 * y + axis]; });
-    build(first, half); // == me + 1
-    const int right = build(first + half, count - half);
-    nodes[me].a = 0;
-    nodes[me].b = right | (axis << 28);
-    return me;
+    build(2 * slot, first, half);
+    build(2 * slot + 1, first + half, count - half);
+  }
+
+  // `fwd_of(i)` = Object::transformation.hom_matrix of sphere i (12 floats)
+  template <typename F> void run(size_t n, F fwd_of) {
+    if (n < 2 || n >= (1u << 24))
+      return;
+    lo.resize(3 * n), hi.resize(3 * n), centre.resize(3 * n);
+    std::vector<float> extent(n);
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; ++i) {
+      const float *fwd = fwd_of(i);
+      extent[i] = 0.f;
+      for (int c = 0; c < 3; ++c) {
+        const double half = std::sqrt(double(fwd[3 * c]) * fwd[3 * c] + double(fwd[3 * c + 1]) * fwd[3 * c + 1] +
+                                      double(fwd[3 * c + 2]) * fwd[3 * c + 2]);
+        const double pad = half * 1e-4 + std::fabs(double(fwd[9 + c])) * 1e-6 + 1e-6;
+        centre[3 * i + c] = fwd[9 + c];
+        lo[3 * i + c] = static_cast<float>(fwd[9 + c] - half - pad);
+        hi[3 * i + c] = static_cast<float>(fwd[9 + c] + half + pad);
+        extent[i] = std::max(extent[i], static_cast<float>(half));
+        clo[c] = std::min(clo[c], centre[3 * i + c]);
+        chi[c] = std::max(chi[c], centre[3 * i + c]);
+      }
+    }
+    const float spread = std::max(chi[0] - clo[0], std::max(chi[1] - clo[1], chi[2] - clo[2]));
+    std::vector<int32_t> big;
+    for (size_t i = 0; i < n; ++i) {
+      const bool finite = std::isfinite(lo[3 * i]) && std::isfinite(lo[3 * i + 1]) && std::isfinite(lo[3 * i + 2]) &&
+                          std::isfinite(hi[3 * i]) && std::isfinite(hi[3 * i + 1]) && std::isfinite(hi[3 * i + 2]);
+      if (!finite || !(extent[i] <= 0.25f * spread))
+        big.push_back(static_cast<int32_t>(i));
+      else
+        order.push_back(static_cast<int32_t>(i));
+    }
+    n_small = static_cast<int>(order.size());
+    if (n_small < 2) {
+      order.clear();
+      n_small = 0;
+      return;
+    }
+    build(1, 0, n_small);
+    order.insert(order.end(), big.begin(), big.end());
+    // quantise on the lattice origin + q * scale, outwards; the device evaluates fmaf(q, scale, origin) in binary32
+    for (int c = 0; c < 3; ++c) {
+      origin[c] = box[6 + c];
+      scale[c] = std::max((box[6 + 3 + c] - box[6 + c]) / 65000.f, 1e-30f);
+    }
+    nodes.assign(leaf.size(), rtd::BvhNode{0u, 0u, 0u, 0u});
+    for (size_t slot = 1; slot < leaf.size(); ++slot) {
+      uint32_t q[6];
+      for (int c = 0; c < 3; ++c) {
+        const float l = box[6 * slot + c], h = box[6 * slot + 3 + c];
+        long ql = std::lround(std::floor((double(l) - origin[c]) / scale[c])) - 1;
+        long qh = std::lround(std::ceil((double(h) - origin[c]) / scale[c])) + 1;
+        ql = std::clamp(ql, 0l, 65535l), qh = std::clamp(qh, 0l, 65535l);
+        while (ql > 0 && std::fmaf(static_cast<float>(ql), scale[c], origin[c]) > l)
+          --ql;
+        while (qh < 65535 && std::fmaf(static_cast<float>(qh), scale[c], origin[c]) < h)
+          ++qh;
+        q[c] = static_cast<uint32_t>(ql), q[3 + c] = static_cast<uint32_t>(qh);
+      }
+      nodes[slot] = rtd::BvhNode{q[0] | (q[3] << 16), q[1] | (q[4] << 16), q[2] | (q[5] << 16), leaf[slot]};
+    }
   }
 };
 
@@ -377,22 +436,17 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     sphere_iso[4 * i + 3] = fwd[0] * fwd[0];
   }
   BvhBuild bvh;
-  if (spheres.size() >= 2) {
-    const size_t n = spheres.size();
-    bvh.lo.resize(3 * n), bvh.hi.resize(3 * n), bvh.centre.resize(3 * n), bvh.order.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-      const float *fwd = d->shape_fwd + 12 * static_cast<size_t>(spheres[i].shape);
-      bvh.order[i] = static_cast<int32_t>(i);
-      for (int c = 0; c < 3; ++c) {
-        const double half = std::sqrt(double(fwd[3 * c]) * fwd[3 * c] + double(fwd[3 * c + 1]) * fwd[3 * c + 1] +
-                                      double(fwd[3 * c + 2]) * fwd[3 * c + 2]);
-        const double pad = half * 1e-4 + std::fabs(double(fwd[9 + c])) * 1e-6 + 1e-6;
-        bvh.centre[3 * i + c] = fwd[9 + c];
-        bvh.lo[3 * i + c] = static_cast<float>(fwd[9 + c] - half - pad);
-        bvh.hi[3 * i + c] = static_cast<float>(fwd[9 + c] + half + pad);
-      }
+  bvh.run(spheres.size(), [&](size_t i) { return d->shape_fwd + 12 * static_cast<size_t>(spheres[i].shape); });
+  std::vector<rtd::ScanRec> bvh_recs, bvh_big;
+  std::vector<float> bvh_iso;
+  for (size_t k = 0; k < bvh.order.size(); ++k) {
+    const size_t i = static_cast<size_t>(bvh.order[k]);
+    if (k < static_cast<size_t>(bvh.n_small)) {
+      bvh_recs.push_back(spheres[i]);
+      bvh_iso.insert(bvh_iso.end(), sphere_iso.begin() + 4 * i, sphere_iso.begin() + 4 * i + 4);
+    } else {
+      bvh_big.push_back(spheres[i]);
     }
-    bvh.build(0, static_cast<int>(n));
   }
   std::vector<uint8_t> needs_uv(d->n_materials);
   for (uint32_t m = 0; m < d->n_materials; ++m)
@@ -440,7 +494,15 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.spheres_all_iso = all_iso ? 1 : 0;
   UP(upload(sc, bvh.nodes, &S.bvh));
   S.n_bvh_nodes = static_cast<int32_t>(bvh.nodes.size());
-  UP(upload(sc, bvh.order, &S.bvh_order));
+  std::memcpy(S.bvh_origin, bvh.origin, sizeof S.bvh_origin);
+  std::memcpy(S.bvh_scale, bvh.scale, sizeof S.bvh_scale);
+  for (int c = 0; c < 3; ++c)
+    S.bvh_inv_scale[c] = 1.f / bvh.scale[c];
+  UP(upload(sc, bvh_recs, &S.bvh_recs));
+  UP(upload(sc, bvh_iso, &S.bvh_iso));
+  UP(upload(sc, bvh_big, &S.bvh_big));
+  S.n_bvh_big = static_cast<int32_t>(bvh_big.size());
+  S.n_bvh_small = bvh.n_small;
   UP(upload(sc, planes, &S.planes));
   UP(upload(sc, cb.tops, &S.csg_tops));
   S.n_spheres = static_cast<int32_t>(spheres.size());
@@ -556,14 +618,34 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   constexpr int BLOCK = 256;
   unsigned grid, block = BLOCK;
   const void *path_kernel = nullptr;
+  size_t dyn_lds = 0;
   if (cfg->mode == RT_MODE_PATH) {
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
     block = rtd::PATH_THREADS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
-    if (use_bvh)
-      path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false, true>)
-                          : reinterpret_cast<const void *>(rtd::k_render_path<true, true>);
+    if (use_bvh) {
+      // The top of the tree goes to LDS next to the workgroup's pool state, within 64 KiB per workgroup.
+      static const int bvh_t = [] { const char *e = std::getenv("RT_BVH_THREADS"); return e ? std::atoi(e) : 512; }();
+      static const int lds_cap = [] { const char *e = std::getenv("RT_BVH_LDS_NODES"); return e ? std::atoi(e) : 1 << 30; }();
+      block = bvh_t == 256 ? 256 : 512;
+      const size_t fixed = block == 256 ? sizeof(rtd::PathShared<256>) : sizeof(rtd::PathShared<512>);
+      const size_t room = (64 * 1024 - fixed - 512) / sizeof(rtd::BvhNode);
+      const size_t n_nodes = static_cast<size_t>(sc->dev.n_bvh_nodes), n_small = static_cast<size_t>(sc->dev.n_bvh_small);
+      p.bvh_lds_nodes = static_cast<int32_t>(std::min<size_t>({n_nodes, room, static_cast<size_t>(std::max(lds_cap, 2))}));
+      p.bvh_iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) ? 1 : 0;
+      const bool split = static_cast<size_t>(p.bvh_lds_nodes) < n_nodes;
+      const bool leaf_lds = !exact && !split && p.bvh_iso && n_nodes + n_small <= room && lds_cap == 1 << 30;
+      p.bvh_lds_spheres = leaf_lds ? static_cast<int32_t>(n_small) : 0;
+#define RT_BVH_K(FAST, T, SPLIT, LEAF) reinterpret_cast<const void *>(rtd::k_render_path_bvh<FAST, T, SPLIT, LEAF>)
+#define RT_BVH_PICK(T)                                                                                              \
+  (exact ? (split ? RT_BVH_K(false, T, true, false) : RT_BVH_K(false, T, false, false))                           \
+         : (split ? RT_BVH_K(true, T, true, false) : (leaf_lds ? RT_BVH_K(true, T, false, true) : RT_BVH_K(true, T, false, false))))
+      path_kernel = block == 256 ? RT_BVH_PICK(256) : RT_BVH_PICK(512);
+#undef RT_BVH_PICK
+#undef RT_BVH_K
+      dyn_lds = static_cast<size_t>(p.bvh_lds_nodes + p.bvh_lds_spheres) * sizeof(rtd::BvhNode);
+    }
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
     if (!exact && !use_bvh && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
@@ -579,7 +661,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
       path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
     }
     int per_cu = 0;
-    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), 0));
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), dyn_lds));
     per_cu = std::max(per_cu, 1);
     const uint64_t want = (p.n_samples + block - 1) / block;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
@@ -602,7 +684,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   case RT_MODE_POINTLIGHT: hipLaunchKernelGGL(rtd::k_render_simple<RT_MODE_POINTLIGHT>, dim3(grid), dim3(BLOCK), 0, stream, sc->dev, p); break;
   default: {
     void *args[] = {&sc->dev, &p};
-    RT_HIP(hipLaunchKernel(path_kernel, dim3(grid), dim3(block), args, 0, stream));
+    RT_HIP(hipLaunchKernel(path_kernel, dim3(grid), dim3(block), args, dyn_lds, stream));
     break;
   }
   }
@@ -622,6 +704,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     if (c[7])
       std::fprintf(stderr, "[rt phases] blocks*iters=%llu rays/iter=%.1f cycles/iter: queue=%.0f scan=%.0f shade=%.0f (100 MHz ticks x?)\n", c[7],
                    double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]));
+#endif
+#ifdef RT_BVH_STATS
+    if (c[8])
+      std::fprintf(stderr, "[rt bvh] grid=%u block=%u lds_nodes=%d lds_spheres=%d per ray: inner=%.1f leaf=%.1f pop=%.1f walk-slots=%.1f leaf-slots=%.1f\n", grid, block,
+                   p.bvh_lds_nodes, p.bvh_lds_spheres, double(c[4]) / double(c[8]), double(c[5]) / double(c[8]), double(c[6]) / double(c[8]),
+                   double(c[7]) / double(c[8]), double(c[9]) / double(c[8]));
 #endif
     float ms = 0.f;
     RT_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));

@@ -555,87 +555,6 @@ template <bool FAST> RT_DEV void scan_spheres(const Scene &s, int n, const Ray &
     sphere_scan_test<FAST>(a, ray, best);
 }
 
-// The same closest hit over the top-level spheres through a bounding-volume hierarchy (RT_FLAG_ACCEL_BVH; not in
-// the reference, which tests every object).  Per-lane traversal with a short stack; a sphere is tested with the
-// very arithmetic the linear scan uses, candidates compare as (t, object index), and the boxes are padded, so the
-// winner is the linear scan's winner — only the number of tests changes.
-template <bool FAST> RT_DEV void bvh_scan_spheres(const Scene &s, const Ray &ray, Best &best) {
-  if (s.n_bvh_nodes == 0)
-    return;
-  const float idx = 1.f / ray.d.x, idy = 1.f / ray.d.y, idz = 1.f / ray.d.z; // +-inf for a zero component
-  int stack[32];
-  int sp = 0, node = 0;
-  for (;;) {
-    const float4 *nv = reinterpret_cast<const float4 *>(s.bvh + node);
-    const float4 n0 = nv[0], n1 = nv[1];
-    const float ax = (n0.x - ray.o.x) * idx, bx = (n1.x - ray.o.x) * idx;
-    const float ay = (n0.y - ray.o.y) * idy, by = (n1.y - ray.o.y) * idy;
-    const float az = (n0.z - ray.o.z) * idz, bz = (n1.z - ray.o.z) * idz;
-    // fminf / fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane): conservative
-    const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
-    bool descend = false;
-    if (tfar >= fmaxf(tnear, 0.f) && tnear <= best.t) {
-      if (b < 0) { // leaf
-        for (int k = 0; k < -b; ++k) {
-          const int i = s.bvh_order[a + k];
-          float t;
-          bool hit;
-          if (FAST) {
-            const float *m = s.spheres[i].inv;
-            const float dx = fmaf(m[0], ray.d.x, fmaf(m[1], ray.d.y, m[2] * ray.d.z));
-            const float dy = fmaf(m[3], ray.d.x, fmaf(m[4], ray.d.y, m[5] * ray.d.z));
-            const float dz = fmaf(m[6], ray.d.x, fmaf(m[7], ray.d.y, m[8] * ray.d.z));
-            const float ox = fmaf(m[0], ray.o.x, fmaf(m[1], ray.o.y, fmaf(m[2], ray.o.z, m[9])));
-            const float oy = fmaf(m[3], ray.o.x, fmaf(m[4], ray.o.y, fmaf(m[5], ray.o.z, m[10])));
-            const float oz = fmaf(m[6], ray.o.x, fmaf(m[7], ray.o.y, fmaf(m[8], ray.o.z, m[11])));
-            const float qa = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-            const float qb = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
-            const float qc = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
-            const float disc = fmaf(qb, qb, -(qa * qc));
-            hit = disc > 0.f;
-            t = 0.f;
-            if (hit) {
-              const float sq = sqrtf(disc), inv_a = 1.f / qa;
-              const float t1 = (-qb - sq) * inv_a, t2 = (-qb + sq) * inv_a;
-              t = t1;
-              if (t1 < ray.tmin) {
-                t = t2;
-                hit = t2 > ray.tmin && t2 < ray.tmax;
-              }
-            }
-          } else {
-            hit = sphere_front_t(s.spheres[i].inv, ray, t);
-          }
-          if (hit) {
-            const int object = s.spheres[i].object;
-            if (t < best.t || (t == best.t && object < best.object)) {
-              best.t = t;
-              best.object = object;
-              best.shape = s.spheres[i].shape;
-            }
-          }
-        }
-      } else {
-        const int right = b & 0x0fffffff, axis = (unsigned)b >> 28;
-        const float da = axis == 0 ? ray.d.x : (axis == 1 ? ray.d.y : ray.d.z);
-        // the left child holds the smaller centroids along the split axis: visit the side the ray comes from first
-        const int first = da >= 0.f ? node + 1 : right, second = da >= 0.f ? right : node + 1;
-        if (sp < 32)
-          stack[sp++] = second;
-        node = first;
-        descend = true;
-      }
-    }
-    if (!descend) {
-      if (sp == 0)
-        break;
-      node = stack[--sp];
-    }
-  }
-}
-
 // Second half of World::ray_intersection (shapes.hpp:547-561) once the spheres have been scanned:
 // planes and CSG objects, ties to the lowest object index, full record for the winner only.
 template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
@@ -692,15 +611,12 @@ template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray,
 
 // World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
 // (strict `<` in insertion order).
-template <bool FAST, bool BVH = false> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
+template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
   Best best;
   best.t = INF_F;
   best.object = 0x7fffffff;
   best.shape = -1;
-  if (BVH)
-    bvh_scan_spheres<FAST>(s, ray, best);
-  else
-    scan_spheres<FAST>(s, s.n_spheres, ray, best);
+  scan_spheres<FAST>(s, s.n_spheres, ray, best);
   return world_finish_hit<FAST>(s, ray, best);
 }
 

@@ -91,7 +91,7 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
 // computes (PMC: 60 % of wave cycles parked), so it is built for 5 waves per SIMD (96 VGPRs, 40 bytes of spills):
 // measured 4 -> 5 waves: C4 147 -> 130 ms, C3 24.2 -> 22.2 ms; 6 and 8 waves spill too much.
 constexpr int PATH_THREADS = 256;
-template <bool FAST, bool BVH = false> __global__ void __launch_bounds__(PATH_THREADS, 5) k_render_path(Scene s, RenderParams p) {
+template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS, 5) k_render_path(Scene s, RenderParams p) {
   __shared__ PathShared<PATH_THREADS> sh;
   PathBlock<PATH_THREADS, FAST> B;
   B.init(p, sh);
@@ -101,7 +101,7 @@ template <bool FAST, bool BVH = false> __global__ void __launch_bounds__(PATH_TH
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
     if (B.active)
-      h = world_ray_intersection<FAST, BVH>(s, B.ray);
+      h = world_ray_intersection<FAST>(s, B.ray);
     B.shade(s, p, sh, h);
   }
   wave_add_counter(p.counters + 1, B.rays);

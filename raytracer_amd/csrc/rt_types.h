@@ -46,11 +46,17 @@ struct CsgProgEntry {  // RPN program "is point inside this subtree?"
   int32_t path_len;
 };
 
-struct BvhNode {       // 32 B: bounding-volume hierarchy over the top-level spheres (optional mode, RT_FLAG_ACCEL_BVH)
-  float lo[3];
-  int32_t a;           // leaf: first entry in bvh_order[]; inner: unused (the left child is the next node)
-  float hi[3];
-  int32_t b;           // leaf: -(number of spheres); inner: right child index | split axis << 28
+// Bounding-volume hierarchy over the top-level spheres (optional mode, RT_FLAG_ACCEL_BVH): a binary tree in HEAP order
+// (root = slot 1, children of n = 2n, 2n + 1, slot 0 unused), so that traversal needs no stack — see rt_bvh.h.
+// One node = 16 bytes: the box quantised to 16 bits per bound on the lattice bvh_origin + q * bvh_scale (rounded
+// outwards), and the leaf range.
+#ifndef RT_BVH_LEAF_MAX
+#define RT_BVH_LEAF_MAX 4
+#endif
+constexpr int BVH_LEAF_MAX = RT_BVH_LEAF_MAX; // spheres per leaf
+struct BvhNode {
+  uint32_t x, y, z;    // per axis: lower bound | upper bound << 16
+  uint32_t leaf;       // inner node: 0; leaf: number of spheres << 24 | first position in bvh_recs[] / bvh_iso[]
 };
 
 struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit shape's material in ONE load round trip
@@ -68,8 +74,13 @@ struct Scene {
   int32_t wide_first, wide_rows;
   const float *sphere_iso;        // [n_spheres][4] world centre + r^2, valid iff spheres_all_iso
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
-  const BvhNode *bvh; int32_t n_bvh_nodes;   // depth-first order, node 0 = root; 0 nodes: no hierarchy
-  const int32_t *bvh_order;       // positions in spheres[] grouped by leaf
+  // RT_FLAG_ACCEL_BVH (rt_bvh.h): heap of n_bvh_nodes slots (0: no hierarchy); the spheres inside it regrouped by
+  // leaf (records, and centre + r^2 when spheres_all_iso); the spheres too big for it, scanned linearly first
+  const BvhNode *bvh; int32_t n_bvh_nodes;
+  float bvh_origin[3], bvh_scale[3], bvh_inv_scale[3];
+  const ScanRec *bvh_recs;
+  const float *bvh_iso;
+  const ScanRec *bvh_big; int32_t n_bvh_big, n_bvh_small;
   const ScanRec *planes;  int32_t n_planes;
   const CsgTop *csg_tops; int32_t n_csg_tops;
   int32_t n_objects;
@@ -134,6 +145,8 @@ struct RenderParams {
   // pool[(b * NODE_WORDS + w) * pool_cap + i]   (rt_path.h)
   float *pool;
   int32_t pool_cap;
+  // RT_FLAG_ACCEL_BVH: heap slots and leaf spheres staged in LDS; whether leaves use the (centre, r^2) form (rt_bvh.h)
+  int32_t bvh_lds_nodes, bvh_lds_spheres, bvh_iso;
 };
 
 } // namespace rtd

@@ -8,7 +8,8 @@ import os
 
 from . import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraytracer_amd.so")
+# RAYTRACER_AMD_LIB names another build of the same library (an instrumented one, scripts/bvh_stats.sh)
+LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraytracer_amd.so")
 
 _dll = None
 

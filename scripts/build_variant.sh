@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds an instrumented / re-parameterised copy of the library next to the product one:
+#   scripts/build_variant.sh NAME -DRT_BVH_STATS ...   ->  raytracer_amd/csrc/build/variants/NAME/libraytracer_amd.so
+# Use it with RAYTRACER_AMD_LIB=<that path> (raytracer_amd/lib.py).  Only rt_api.hip is recompiled.
+set -e
+cd "$(dirname "$0")/../raytracer_amd/csrc"
+name=$1; shift
+make -s ../libraytracer_amd.so
+out=build/variants/$name
+mkdir -p "$out"
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -fvisibility=hidden "$@" -c rt_api.hip -o "$out/rt_api.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/rt_api.o" build/rt_wide_iso.o build/rt_wide_gen.o -o "$out/libraytracer_amd.so"
+echo "$PWD/$out/libraytracer_amd.so"
