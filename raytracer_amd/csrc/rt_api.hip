@@ -625,17 +625,19 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     block = rtd::PATH_THREADS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
     if (use_bvh) {
-      // The top of the tree goes to LDS next to the workgroup's pool state, within 64 KiB per workgroup.
-      static const int bvh_t = [] { const char *e = std::getenv("RT_BVH_THREADS"); return e ? std::atoi(e) : 512; }();
-      static const int lds_cap = [] { const char *e = std::getenv("RT_BVH_LDS_NODES"); return e ? std::atoi(e) : 1 << 30; }();
-      block = bvh_t == 256 ? 256 : 512;
-      const size_t fixed = block == 256 ? sizeof(rtd::PathShared<256>) : sizeof(rtd::PathShared<512>);
-      const size_t room = (64 * 1024 - fixed - 512) / sizeof(rtd::BvhNode);
+      // The tree (or its top) and, if they fit too, the leaf spheres go to LDS next to the workgroup's pool state:
+      // 256 lanes when all of it fits 40 KiB (4 workgroups per CU), else 512 lanes within 64 KiB (2 per CU) — 4 waves
+      // per SIMD either way (measured: 256 lanes are 5-8 % faster where they fit, 20 % slower at 3 workgroups per CU).
       const size_t n_nodes = static_cast<size_t>(sc->dev.n_bvh_nodes), n_small = static_cast<size_t>(sc->dev.n_bvh_small);
-      p.bvh_lds_nodes = static_cast<int32_t>(std::min<size_t>({n_nodes, room, static_cast<size_t>(std::max(lds_cap, 2))}));
       p.bvh_iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) ? 1 : 0;
+      const bool want_leaves = !exact && p.bvh_iso;
+      const size_t room256 = (40 * 1024 - sizeof(rtd::PathShared<256>) - 512) / sizeof(rtd::BvhNode);
+      const size_t room512 = (64 * 1024 - sizeof(rtd::PathShared<512>) - 512) / sizeof(rtd::BvhNode);
+      block = n_nodes + (want_leaves ? n_small : 0) <= room256 ? 256u : 512u;
+      const size_t room = block == 256 ? room256 : room512;
+      p.bvh_lds_nodes = static_cast<int32_t>(std::min(n_nodes, room));
       const bool split = static_cast<size_t>(p.bvh_lds_nodes) < n_nodes;
-      const bool leaf_lds = !exact && !split && p.bvh_iso && n_nodes + n_small <= room && lds_cap == 1 << 30;
+      const bool leaf_lds = want_leaves && !split && n_nodes + n_small <= room;
       p.bvh_lds_spheres = leaf_lds ? static_cast<int32_t>(n_small) : 0;
 #define RT_BVH_K(FAST, T, SPLIT, LEAF) reinterpret_cast<const void *>(rtd::k_render_path_bvh<FAST, T, SPLIT, LEAF>)
 #define RT_BVH_PICK(T)                                                                                              \

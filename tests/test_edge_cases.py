@@ -143,3 +143,47 @@ def test_two_worlds_and_repeated_renders_do_not_interfere(gpu):
     ib2, ia2 = tb.fire_all_rays(wb, mode), ta.fire_all_rays(wa, mode)
     wa.close(), wb.close()
     assert np.array_equal(ia1, ia2) and np.array_equal(ib1, ib2)
+
+
+# ---- RT_FLAG_ACCEL_BVH on worlds that stress its corner cases ----
+
+def _same_with_and_without_bvh(gpu, scene, w=40, h=26, aa=2, **kw):
+    world = gpu.DeviceWorld(scene)
+    t = gpu.GpuImageTracer(w, h, scene.camera, aa)
+    linear = t.fire_all_rays(world, gpu.RenderMode("path", exact=True, **kw))
+    rays = int(t.last_stats.rays)
+    bvh = t.fire_all_rays(world, gpu.RenderMode("path", exact=True, bvh=True, **kw))
+    rays_bvh = int(t.last_stats.rays)
+    world.close()
+    assert np.array_equal(linear, bvh) and rays == rays_bvh
+
+
+@pytest.mark.parametrize("scene_kw", [dict(csg_only=True), dict(n_spheres=0), dict(n_spheres=1)])
+def test_bvh_flag_on_worlds_without_a_hierarchy(gpu, scene_kw):
+    """No tree is built for fewer than two small spheres: the flag must then change nothing."""
+    _same_with_and_without_bvh(gpu, small_world(**scene_kw), n_rays=3, max_depth=3)
+
+
+def test_bvh_with_coincident_spheres_planes_and_csg(gpu):
+    """Equal hit distances (the same sphere listed three times, in a different order than the tree sorts them) fall to
+    the lowest object index, as in World::ray_intersection's strict `<`; planes and a CSG object share the world."""
+    b = SceneBuilder()
+    sky = b.material("diffuse", b.pigment_uniform((0, 0, 0)), b.pigment_uniform((0.4, 0.5, 0.9)))
+    mats = [b.material("diffuse", b.pigment_uniform(c)) for c in [(0.8, 0.2, 0.1), (0.1, 0.8, 0.2), (0.2, 0.1, 0.8)]]
+    mirror = b.material("specular", b.pigment_uniform((0.7, 0.7, 0.7)))
+    b.plane(compose(translation([0, 0, -1])), mats[1])
+    b.sphere(compose(scaling([30, 30, 30])), sky)
+    rng = np.random.default_rng(5)
+    twin = compose(translation([0.5, 0.2, -0.2]), scaling([0.45, 0.45, 0.45]))
+    for k in range(40):
+        if k in (3, 17, 31):
+            b.sphere(twin, mats[k % 3])                     # three coincident spheres with different colours
+        else:
+            c = rng.uniform([-0.5, -2.0, -0.8], [3.0, 2.0, 1.0])
+            r = float(rng.uniform(0.08, 0.25))
+            b.sphere(compose(translation(c.tolist()), scaling([r, r * float(rng.uniform(0.5, 1.5)), r])), mirror if k % 5 == 0 else mats[k % 3])
+    c1 = b.sphere(compose(translation([1.5, -1.0, 0.0]), scaling([0.6, 0.6, 0.6])), mats[0], norender=True)
+    c2 = b.sphere(compose(translation([1.8, -0.8, 0.2]), scaling([0.5, 0.5, 0.5])), mirror, norender=True)
+    b.csg(c1, c2, "difference")
+    b.camera = camera()
+    _same_with_and_without_bvh(gpu, b.build(), n_rays=3, roulette=2, max_depth=4, seq_number=77)

@@ -297,10 +297,12 @@ def test_path_wide_kernel_row_bands_and_determinism():
 
 # ---- optional BVH mode (RT_FLAG_ACCEL_BVH): same hits as the linear scan, fewer tests ----
 
-@pytest.mark.parametrize("kind,n", [("iso", 70), ("iso", 600), ("general", 300), ("iso", 4000)])
+@pytest.mark.parametrize("kind,n", [("iso", 2), ("iso", 5), ("iso", 70), ("iso", 600), ("general", 300), ("iso", 4000), ("iso", 5000)])
 def test_bvh_mode_finds_the_linear_scan_winner(kind, n):
     """With the unfused arithmetic every sphere test gives the same t through the hierarchy as in the linear scan and
-    candidates compare as (t, object index), so the two path renders must be IDENTICAL, ray count included."""
+    candidates compare as (t, object index), so the two path renders must be IDENTICAL, ray count included.
+    n = 2, 5: a root that is a leaf / one split; n = 5000: the heap outgrows LDS (deep levels read from HBM); the sky
+    sphere of the synthetic scenes is one of the spheres kept out of the tree."""
     from raytracer_amd.synth import synthetic_scene
     scene = synthetic_scene(n)[0] if kind == "iso" else _ellipsoid_world(n)
     world = DeviceWorld(scene)
