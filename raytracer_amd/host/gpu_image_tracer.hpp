@@ -40,6 +40,7 @@ struct GpuRenderMode {
   Color background = BLACK;
   Color ambient = DARK_GREY;
   int max_mirror_bounces = 64; // the reference's pointlight mirror loop has no cap and can spin forever
+  uint32_t flags = 0;          // RT_FLAG_* of include/raytracer_amd.h (e.g. RT_FLAG_ACCEL_BVH)
 
   static GpuRenderMode onoff() { return GpuRenderMode{RT_MODE_ONOFF}; }
   static GpuRenderMode flat() { return GpuRenderMode{RT_MODE_FLAT}; }
@@ -85,6 +86,7 @@ public:
     cfg.background[0] = mode.background.r, cfg.background[1] = mode.background.g, cfg.background[2] = mode.background.b;
     cfg.ambient[0] = mode.ambient.r, cfg.ambient[1] = mode.ambient.g, cfg.ambient[2] = mode.ambient.b;
     cfg.max_mirror_bounces = mode.max_mirror_bounces;
+    cfg.flags = mode.flags;
     cfg.rng_mode = RT_RNG_PER_NODE_STREAMS;
     static_assert(sizeof(Color) == 3 * sizeof(float), "HdrImage::pixels must be packed rgb floats");
     float *pixels = reinterpret_cast<float *>(image->pixels.data());

@@ -4,7 +4,7 @@
 // the worked example of INTEGRATION.md and the end-to-end test of the C++ flattener.
 //
 //   raytracer_gpu <scene.txt> -o out.pfm [--mode onoff|flat|pointlight|path] [--width W] [--height H]
-//                 [--aa N] [--n_rays N] [--roulette N] [--max-depth N] [--seq N] [--define name=value]...
+//                 [--aa N] [--n_rays N] [--roulette N] [--max-depth N] [--seq N] [--bvh] [--define name=value]...
 #include "colors.hpp"
 #include "geometry.hpp"
 #include "renderers.hpp"
@@ -25,6 +25,7 @@ int main(int argc, char **argv) {
   std::string scene_file = argv[1], out, mode = "flat";
   int width = 1280, height = 960, aa = 1, n_rays = 10, roulette = 3, max_depth = 5;
   uint64_t seq = 54;
+  bool bvh = false;
   std::unordered_map<std::string, float> defines;
   for (int i = 2; i < argc; ++i) {
     std::string s = argv[i];
@@ -44,6 +45,7 @@ int main(int argc, char **argv) {
     else if (s == "--roulette") roulette = std::stoi(next());
     else if (s == "--max-depth") max_depth = std::stoi(next());
     else if (s == "--seq") seq = std::stoull(next());
+    else if (s == "--bvh") bvh = true;
     else if (s == "--define") {
       std::string d = next();
       auto eq = d.find('=');
@@ -81,6 +83,8 @@ int main(int argc, char **argv) {
     else if (mode == "pointlight") m = raytracer_amd::GpuRenderMode::pointlight();
     else if (mode == "path") m = raytracer_amd::GpuRenderMode::path(n_rays, roulette, max_depth, seq);
     else throw std::invalid_argument("unknown mode " + mode);
+    if (bvh)
+      m.flags |= RT_FLAG_ACCEL_BVH;
 
     auto t0 = std::chrono::steady_clock::now();
     tracer.fire_all_rays(scene.world, m);

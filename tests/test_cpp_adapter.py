@@ -124,3 +124,23 @@ def test_cpp_route_reports_errors_like_the_reference(tmp_path):
     txt.write_text("sphere(identity, no_such_material)\n")
     res = subprocess.run([GPU_BIN, str(txt), "-o", str(tmp_path / "o.pfm")], capture_output=True, text=True, timeout=60)
     assert res.returncode != 0 and res.stderr.strip()
+
+
+@needs_bin
+@pytest.mark.gpu
+def test_cpp_route_with_the_bvh_flag(tmp_path):
+    """`--bvh` (GpuRenderMode::flags = RT_FLAG_ACCEL_BVH) on the synthetic scene text parsed by the reference's own parser:
+    same frame and ray count as the Python route with the flag, and as the C++ route without it (the FMA kernels test a
+    sphere with the same arithmetic through the hierarchy and in the wide scan)."""
+    from raytracer_amd.synth import synthetic_scene
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    scene, text = synthetic_scene(96)
+    args = ("--mode", "path", "--width", 64, "--height", 40, "--aa", 2, "--n_rays", 3, "--roulette", 2, "--max-depth", 3, "--seq", 5)
+    img_bvh, info_bvh = run_gpu_bin(tmp_path, text, *args, "--bvh")
+    img_lin, info_lin = run_gpu_bin(tmp_path, text, *args)
+    world = DeviceWorld(scene)
+    tracer = GpuImageTracer(64, 40, scene.camera, 2)
+    img_py = tracer.fire_all_rays(world, RenderMode("path", n_rays=3, roulette=2, max_depth=3, seq_number=5, bvh=True))
+    world.close()
+    assert np.array_equal(img_bvh, img_py) and info_bvh["rays"] == tracer.last_stats.rays
+    assert np.array_equal(img_bvh, img_lin) and info_bvh["rays"] == info_lin["rays"]
