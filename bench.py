@@ -182,7 +182,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -190,19 +190,23 @@ def main():
         tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
         ev[k][1].record()
         gather()
+        ev[k][2].record()  # after the gather: torch makes the current stream wait for the collective
         if args.steps > 1:
             torch.cuda.current_stream().synchronize()
             log(f"step {k + 1}/{args.steps} done")
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
+    gather_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps  # on rank 0 this includes waiting for the slowest rank
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=gather_dev)
     r = torch.tensor([rays_local, samples_local], dtype=torch.int64, device=gather_dev)
+    g = torch.tensor([gather_ms], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(g, op=dist.ReduceOp.MIN)  # the rank that finished rendering last waits for nobody: the transfer itself
     elapsed, kernel_ms_max = float(t[0]), float(t[1])
     rays_total, samples_total = int(r[0]), int(r[1])
 
@@ -231,6 +235,7 @@ def main():
                        "rays_per_sample": rays_total / max(samples_total, 1),
                        "parallelism": f"rows-cyclic-x{world_size}" if world_size > 1 else "single"},
             "kernel_ms_per_step_max_rank": kernel_ms_max,
+            "gather_ms_per_step": {"rank0_including_wait_for_slowest_rank": gather_ms, "min_over_ranks": float(g[0])},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": pmc_traffic(args),
                          "kernel": "rtd::k_render_path_wide<ISO,K,W> (+ k_resolve, <0.1 %)", "flops_per_ray": f_ray,
