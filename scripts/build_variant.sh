@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds an instrumented / re-parameterised copy of the library next to the product one:
 #   scripts/build_variant.sh NAME -DRT_BVH_STATS ...   ->  raytracer_amd/csrc/build/variants/NAME/libraytracer_amd.so
-# Use it with RAYTRACER_AMD_LIB=<that path> (raytracer_amd/lib.py).  Only rt_api.hip is recompiled.
+# Use it with RAYTRACER_AMD_LIB=<that path> (raytracer_amd/lib.py).  Only rt_api.hip is recompiled, unless ALL=1 is set
+# (then the wide-kernel translation units too, e.g. for -DRT_PROFILE_PHASES).
 set -e
 cd "$(dirname "$0")/../raytracer_amd/csrc"
 name=$1; shift
@@ -9,5 +10,13 @@ make -s ../libraytracer_amd.so
 out=build/variants/$name
 mkdir -p "$out"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -fvisibility=hidden "$@" -c rt_api.hip -o "$out/rt_api.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/rt_api.o" build/rt_wide_iso.o build/rt_wide_gen.o -o "$out/libraytracer_amd.so"
+wide="build/rt_wide_iso.o build/rt_wide_gen.o"
+if [ -n "$ALL" ]; then
+  for f in rt_wide_iso rt_wide_gen; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -fvisibility=hidden "$@" -c $f.hip -o "$out/$f.o" &
+  done
+  wait
+  wide="$out/rt_wide_iso.o $out/rt_wide_gen.o"
+fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/rt_api.o" $wide -o "$out/libraytracer_amd.so"
 echo "$PWD/$out/libraytracer_amd.so"
