@@ -95,6 +95,7 @@ struct BvhBuild {
   std::vector<rtd::BvhNode> nodes;
   float origin[3] = {0.f, 0.f, 0.f}, scale[3] = {1.f, 1.f, 1.f};
   int n_small = 0;
+  std::vector<char> is_big;          // per sphere: too big for the tree (and for the register rows of the wide kernel)
 
   void build(size_t slot, int first, int count) {
     if (box.size() < 6 * (slot + 1))
@@ -127,6 +128,7 @@ struct BvhBuild {
 
   // `fwd_of(i)` = Object::transformation.hom_matrix of sphere i (12 floats)
   template <typename F> void run(size_t n, F fwd_of) {
+    is_big.assign(n, 0);
     if (n < 2 || n >= (1u << 24))
       return;
     lo.resize(3 * n), hi.resize(3 * n), centre.resize(3 * n);
@@ -152,9 +154,10 @@ struct BvhBuild {
     for (size_t i = 0; i < n; ++i) {
       const bool finite = std::isfinite(lo[3 * i]) && std::isfinite(lo[3 * i + 1]) && std::isfinite(lo[3 * i + 2]) &&
                           std::isfinite(hi[3 * i]) && std::isfinite(hi[3 * i + 1]) && std::isfinite(hi[3 * i + 2]);
-      if (!finite || !(extent[i] <= 0.25f * spread))
+      if (!finite || !(extent[i] <= 0.25f * spread)) {
         big.push_back(static_cast<int32_t>(i));
-      else
+        is_big[i] = 1;
+      } else
         order.push_back(static_cast<int32_t>(i));
     }
     n_small = static_cast<int>(order.size());
@@ -448,6 +451,33 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       bvh_big.push_back(spheres[i]);
     }
   }
+  // Wide path kernel (rt_wide.h): which spheres sit in the register rows and which are scanned per lane.  Per lane go
+  // the big ones (the line of nearly every ray meets a sky sphere, and a hit in the transposed scan costs the whole
+  // wave ~50 instructions where a per-lane test costs 33 for 64 rays) and a leftover that would fill less than a
+  // quarter of a register row (a fuller leftover is cheaper as one more, partly empty, row).  Both lists ascend.
+  std::vector<rtd::ScanRec> wide_recs, wide_lane;
+  std::vector<float> wide_iso;
+  {
+    std::vector<size_t> rest;
+    std::vector<char> lane(spheres.size(), 0);
+    for (size_t i = 0; i < spheres.size(); ++i)
+      if (bvh.is_big[i])
+        lane[i] = 1;
+      else
+        rest.push_back(i);
+    const size_t leftover = rest.size() % 64;
+    if (leftover < 16)
+      for (size_t k = 0; k < leftover; ++k)
+        lane[rest[k]] = 1;
+    for (size_t i = 0; i < spheres.size(); ++i) {
+      if (lane[i]) {
+        wide_lane.push_back(spheres[i]);
+      } else {
+        wide_recs.push_back(spheres[i]);
+        wide_iso.insert(wide_iso.end(), sphere_iso.begin() + 4 * i, sphere_iso.begin() + 4 * i + 4);
+      }
+    }
+  }
   std::vector<uint8_t> needs_uv(d->n_materials);
   for (uint32_t m = 0; m < d->n_materials; ++m)
     needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
@@ -490,7 +520,6 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   if ((st = (expr)) != RT_OK)                                                                              \
   return bail(st)
   UP(upload(sc, spheres, &S.spheres));
-  UP(upload(sc, sphere_iso, &S.sphere_iso));
   S.spheres_all_iso = all_iso ? 1 : 0;
   UP(upload(sc, bvh.nodes, &S.bvh));
   S.n_bvh_nodes = static_cast<int32_t>(bvh.nodes.size());
@@ -506,11 +535,12 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, planes, &S.planes));
   UP(upload(sc, cb.tops, &S.csg_tops));
   S.n_spheres = static_cast<int32_t>(spheres.size());
-  // A leftover of 16 or more spheres is cheaper as one more (partly empty) register row (11 wave instructions
-  // per ray) than scanned lane by lane (33 instructions per sphere and lane).
-  const int leftover = S.n_spheres % 64;
-  S.wide_first = leftover >= 16 ? 0 : leftover;
-  S.wide_rows = (S.n_spheres - S.wide_first + 63) / 64;
+  UP(upload(sc, wide_recs, &S.wide_recs));
+  UP(upload(sc, wide_iso, &S.wide_iso));
+  UP(upload(sc, wide_lane, &S.wide_lane));
+  S.n_wide = static_cast<int32_t>(wide_recs.size());
+  S.wide_rows = (S.n_wide + 63) / 64;
+  S.n_wide_lane = static_cast<int32_t>(wide_lane.size());
   S.n_planes = static_cast<int32_t>(planes.size());
   S.n_csg_tops = static_cast<int32_t>(cb.tops.size());
   S.n_objects = static_cast<int32_t>(d->n_objects);
@@ -650,7 +680,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     }
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
-    if (!exact && !use_bvh && sc->dev.n_spheres >= 64) { // measured: from 64 top-level spheres on, the wide kernel beats the per-lane scan
+    if (!exact && !use_bvh && sc->dev.n_wide >= 64) { // measured: from 64 spheres in the register rows on, the wide kernel beats the per-lane scan
       const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.

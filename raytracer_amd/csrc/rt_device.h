@@ -540,15 +540,15 @@ template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &r
 // The scan over the top-level spheres, in World::objects order (strict `<`: the lowest index wins
 // ties).  Records ping-pong between two SGPR sets so that the scalar load of the next record is in
 // flight while the lanes test the current one.
-template <bool FAST> RT_DEV void scan_spheres(const Scene &s, int n, const Ray &ray, Best &best) {
+template <bool FAST> RT_DEV void scan_spheres(const ScanRec *recs, int n, const Ray &ray, Best &best) {
   if (n <= 0)
     return;
-  RecRegs a = load_rec(s.spheres, 0);
+  RecRegs a = load_rec(recs, 0);
   int i = 0;
   for (; i + 1 < n; i += 2) {
-    const RecRegs b = load_rec(s.spheres, i + 1);
+    const RecRegs b = load_rec(recs, i + 1);
     sphere_scan_test<FAST>(a, ray, best);
-    a = load_rec(s.spheres, min(i + 2, n - 1));
+    a = load_rec(recs, min(i + 2, n - 1));
     sphere_scan_test<FAST>(b, ray, best);
   }
   if (i < n)
@@ -616,7 +616,7 @@ template <bool FAST> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray
   best.t = INF_F;
   best.object = 0x7fffffff;
   best.shape = -1;
-  scan_spheres<FAST>(s, s.n_spheres, ray, best);
+  scan_spheres<FAST>(s.spheres, s.n_spheres, ray, best);
   return world_finish_hit<FAST>(s, ray, best);
 }
 

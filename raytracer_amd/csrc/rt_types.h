@@ -69,10 +69,11 @@ struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit sha
 struct Scene {
   // scan lists
   const ScanRec *spheres; int32_t n_spheres;
-  // wide path kernel: spheres [wide_first, n_spheres) are held in registers as wide_rows rows of 64 (the last
-  // row may be partly empty), the first wide_first ones are scanned per lane (rt_wide.h)
-  int32_t wide_first, wide_rows;
-  const float *sphere_iso;        // [n_spheres][4] world centre + r^2, valid iff spheres_all_iso
+  // wide path kernel (rt_wide.h): the spheres held in registers, regrouped in ascending object order as wide_rows rows
+  // of 64 (the last one may be partly empty) — records, and world centre + r^2 (valid iff spheres_all_iso); and the
+  // ones scanned per lane instead (big spheres, a short leftover), ascending too
+  const ScanRec *wide_recs; const float *wide_iso; int32_t n_wide, wide_rows;
+  const ScanRec *wide_lane; int32_t n_wide_lane;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   // RT_FLAG_ACCEL_BVH (rt_bvh.h): heap of n_bvh_nodes slots (0: no hierarchy); the spheres inside it regrouped by
   // leaf (records, and centre + r^2 when spheres_all_iso); the spheres too big for it, scanned linearly first

@@ -39,7 +39,7 @@ template <int K> struct WideSlots<true, K> {
   float cx[K], cy[K], cz[K], r2[K];
   RT_DEV void load(const Scene &s, int k, int sphere, bool valid) {
     if (valid) {
-      const float4 v = reinterpret_cast<const float4 *>(s.sphere_iso)[sphere];
+      const float4 v = reinterpret_cast<const float4 *>(s.wide_iso)[sphere];
       cx[k] = v.x, cy[k] = v.y, cz[k] = v.z, r2[k] = v.w;
     } else { // empty slot: c = |oc|^2 + 1 makes disc <= -a < 0 (Cauchy-Schwarz), never a hit
       cx[k] = cy[k] = cz[k] = 0.f;
@@ -62,7 +62,7 @@ template <int K> struct WideSlots<false, K> {
   float a_[K];
   RT_DEV void load(const Scene &s, int k, int sphere, bool valid) {
     if (valid) {
-      const float4 *v = reinterpret_cast<const float4 *>(s.spheres[sphere].inv);
+      const float4 *v = reinterpret_cast<const float4 *>(s.wide_recs[sphere].inv);
       const float4 v0 = v[0], v1 = v[1], v2 = v[2];
       m[k][0] = v0.x, m[k][1] = v0.y, m[k][2] = v0.z, m[k][3] = v0.w;
       m[k][4] = v1.x, m[k][5] = v1.y, m[k][6] = v1.z, m[k][7] = v1.w;
@@ -149,10 +149,9 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
   __shared__ PathShared<WIDE_THREADS> sh;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // Spheres [wide_first, n_spheres) are held in registers as n_rows rows of 64 (the last one may be partly
-  // empty); the first wide_first (< 16) spheres of the list are scanned per lane with the other objects.  Row r of a
-  // pass belongs to wave r % W, register row r / W; rows past n_rows are never-hit dummies.
-  const int wide_first = s.wide_first;
+  // The spheres of s.wide_recs / s.wide_iso are held in registers as n_rows rows of 64 (the last one may be partly
+  // empty); the spheres of s.wide_lane (big ones, a short leftover) are tested per lane with the other objects.  Row r
+  // of a pass belongs to wave r % W, register row r / W; rows past n_rows are never-hit dummies.
   const int n_rows = s.wide_rows;
   const int n_pass = (n_rows + K * WIDE_WAVES - 1) / (K * WIDE_WAVES);
   PathBlock<WIDE_THREADS, true> L;
@@ -196,12 +195,12 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
 
     // -- every lane is K spheres: all waves test every queued ray ----------------------------------
     for (int pass = 0; pass < n_pass; ++pass) {
-      const int first = wide_first + pass * K * WIDE_WAVES * 64;
+      const int first = pass * K * WIDE_WAVES * 64;
       // (Re)load this pass's spheres: 16 bytes per sphere from L2, once per iteration — cheaper than keeping
       // K rows alive across the shading phase, where they would push its working set out of the register file.
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, first + (k * WIDE_WAVES + wave) * 64 + lane < s.n_spheres);
+        slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, first + (k * WIDE_WAVES + wave) * 64 + lane < s.n_wide);
       auto test_ray = [&](const WideRay &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
       // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
       // the lanes test the current one.
@@ -230,14 +229,14 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       best.t = INF_F;
       best.object = 0x7fffffff;
       best.shape = -1;
-      scan_spheres<true>(s, wide_first, L.ray, best); // the few spheres that did not fill a register row
-      if (key != ~0ull) { // sphere list order == object order, so the key's tie-break is the reference's
-        const int sphere = (int)(unsigned)(key & 0xffffffffull);
+      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best); // in object order: strict `<` among them
+      if (key != ~0ull) { // positions in the register rows ascend with the object index: the key's tie-break is the reference's
+        const int2 ids = *reinterpret_cast<const int2 *>(&s.wide_recs[(int)(unsigned)(key & 0xffffffffull)].object); // {object, shape}
         const float t = __uint_as_float((unsigned)(key >> 32));
-        if (t < best.t) { // a register-held sphere has a higher index than any scanned one: strict <
+        if (t < best.t || (t == best.t && ids.x < best.object)) {
           best.t = t;
-          best.object = s.spheres[sphere].object;
-          best.shape = s.spheres[sphere].shape;
+          best.object = ids.x;
+          best.shape = ids.y;
         }
       }
       h = world_finish_hit<true>(s, L.ray, best);
