@@ -46,13 +46,13 @@ def flops_per_ray(n_spheres_top: int, n_planes_top: int) -> float:
 
 def pmc_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the committed counter passes of THIS configuration
-    (scripts/pmc_run.sh -> profiles/r1/f_n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the run's two
+    (scripts/pmc_run.sh -> profiles/r1/g_n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the run's two
     launches, each in its own rocprofv3 --pmc pass).  FETCH_SIZE is taken as reported (gfx950 tallies 64 B per 128-B
     request for wide streaming reads; the node-stack reads here are dword gathers, uncalibrated).  None for any other
     configuration: counters cannot be read from inside the timed run."""
     default = (args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
                and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
-    path = os.path.join(ROOT, "profiles", "r1", "f_n512_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r1", "g_n512_pmc.json")
     if not default or not os.path.exists(path):
         return None
     with open(path) as f:
