@@ -656,13 +656,14 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
     if (use_bvh) {
       // The tree (or its top) and, if they fit too, the leaf spheres go to LDS next to the workgroup's pool state:
-      // 256 lanes when all of it fits 40 KiB (4 workgroups per CU), else 512 lanes within 64 KiB (2 per CU) — 4 waves
+      // 256 lanes when all of it fits 40 KiB (4 workgroups per CU), else 512 lanes within 72 KiB (2 per CU) — 4 waves
       // per SIMD either way (measured: 256 lanes are 5-8 % faster where they fit, 20 % slower at 3 workgroups per CU).
       const size_t n_nodes = static_cast<size_t>(sc->dev.n_bvh_nodes), n_small = static_cast<size_t>(sc->dev.n_bvh_small);
       p.bvh_iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) ? 1 : 0;
       const bool want_leaves = !exact && p.bvh_iso;
-      const size_t room256 = (40 * 1024 - sizeof(rtd::PathShared<256>) - 512) / sizeof(rtd::BvhNode);
-      const size_t room512 = (64 * 1024 - sizeof(rtd::PathShared<512>) - 512) / sizeof(rtd::BvhNode);
+      // per workgroup besides the tree: one 8-byte key per ray and 64 donor lanes per wave (rt_bvh.h) = 12 bytes per lane
+      const size_t room256 = (40 * 1024 - sizeof(rtd::PathShared<256>) - 512 - 12 * 256) / sizeof(rtd::BvhNode);
+      const size_t room512 = (72 * 1024 - sizeof(rtd::PathShared<512>) - 512 - 12 * 512) / sizeof(rtd::BvhNode);
       block = n_nodes + (want_leaves ? n_small : 0) <= room256 ? 256u : 512u;
       const size_t room = block == 256 ? room256 : room512;
       p.bvh_lds_nodes = static_cast<int32_t>(std::min(n_nodes, room));
@@ -676,7 +677,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
       path_kernel = block == 256 ? RT_BVH_PICK(256) : RT_BVH_PICK(512);
 #undef RT_BVH_PICK
 #undef RT_BVH_K
-      dyn_lds = static_cast<size_t>(p.bvh_lds_nodes + p.bvh_lds_spheres) * sizeof(rtd::BvhNode);
+      dyn_lds = static_cast<size_t>(p.bvh_lds_nodes + p.bvh_lds_spheres) * sizeof(rtd::BvhNode) + 12 * static_cast<size_t>(block);
+      if (dyn_lds > 32 * 1024) // above what a kernel gets without asking
+        RT_HIP(hipFuncSetAttribute(path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn_lds)));
     }
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
@@ -739,9 +742,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
 #endif
 #ifdef RT_BVH_STATS
     if (c[8])
-      std::fprintf(stderr, "[rt bvh] grid=%u block=%u lds_nodes=%d lds_spheres=%d per ray: inner=%.1f leaf=%.1f pop=%.1f walk-slots=%.1f leaf-slots=%.1f\n", grid, block,
+      std::fprintf(stderr, "[rt bvh] grid=%u block=%u lds_nodes=%d lds_spheres=%d per ray: inner=%.1f leaf=%.1f pop=%.1f walk-slots=%.1f leaf-slots=%.1f steals=%.2f\n", grid, block,
                    p.bvh_lds_nodes, p.bvh_lds_spheres, double(c[4]) / double(c[8]), double(c[5]) / double(c[8]), double(c[6]) / double(c[8]),
-                   double(c[7]) / double(c[8]), double(c[9]) / double(c[8]));
+                   double(c[7]) / double(c[8]), double(c[9]) / double(c[8]), double(c[10]) / double(c[8]));
 #endif
     float ms = 0.f;
     RT_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));

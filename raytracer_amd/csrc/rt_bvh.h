@@ -65,12 +65,28 @@ RT_DEV bool bvh_box_hit(const uint4 q, const BvhRay &r, float best_t, float &tne
   return tfar >= fmaxf(tnear, 0.f) && tnear <= best_t;
 }
 
-// Candidates are tracked as (t, leaf position); the object index is only fetched to break a tie, and once for the
-// winner after the traversal.  `seed_object` = the object of the best big sphere (what bt starts from), if any.
-RT_DEV void bvh_accept(const Scene &s, int pos, float t, float &bt, int &bpos, int seed_object) {
-  if (t < bt || (t == bt && s.bvh_recs[pos].object < (bpos >= 0 ? s.bvh_recs[bpos].object : seed_object))) {
-    bt = t;
-    bpos = pos;
+// The best candidate of a ray lives in LDS as one 64-bit key, t bits << 32 | leaf position (t > 0: the bits order like
+// the numbers), because several lanes of the wave may be working on the same ray (bvh_closest_sphere).  Candidates
+// compare as (t, object index) — World::ray_intersection's strict `<` in insertion order; the object index is only
+// fetched to break a tie.  Whatever the order in which lanes offer candidates, the key ends at their minimum.
+constexpr unsigned long long BVH_NO_HIT = 0x7f800000ffffffffull; // t = inf, position -1
+RT_DEV void bvh_accept(const Scene &s, unsigned long long *slot, int pos, float t, float &bt) {
+  unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(slot);
+  for (;;) {
+    const float ot = __uint_as_float((uint32_t)(old >> 32));
+    const int opos = (int)(uint32_t)old;
+    const bool better = t < ot || (t == ot && opos != pos && s.bvh_recs[pos].object < s.bvh_recs[opos].object); // t == ot: opos >= 0
+    if (!better) {
+      bt = fminf(bt, ot);
+      return;
+    }
+    const unsigned long long mine = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)pos;
+    const unsigned long long prev = atomicCAS(slot, old, mine);
+    if (prev == old) {
+      bt = t;
+      return;
+    }
+    old = prev;
   }
 }
 
@@ -117,42 +133,105 @@ RT_DEV bool bvh_gen_front_t(const float *m, const Ray &ray, float &t) {
 }
 
 #ifdef RT_BVH_STATS
-struct BvhStats { unsigned inner, leaf, pop, wave_iters, wave_leaf_iters, rays; };
+struct BvhStats { unsigned inner, leaf, pop, wave_iters, wave_leaf_iters, rays, steals; };
 #define RT_BVH_COUNT(x) (++(x))
 #else
 struct BvhStats {};
 #define RT_BVH_COUNT(x)
 #endif
 
+// Closest sphere of the tree for the rays of one WAVE: lane l enters with its own ray (or none) and leaves with the key
+// of its own ray in res[l].  All 64 lanes must call it (wave-uniform control flow around the call).
+//
+// "While-while": every lane first walks (down, or back up through `trail`) until it sits on a leaf or is done — LDS
+// reads only —, then the lanes that reached a leaf test its spheres together, so the long-latency sphere loads are paid
+// once per leaf visit of the slowest lane, not once per step.
+//
+// Subtree stealing inside the wave: the slowest of 64 incoherent rays takes 2-4x the mean number of steps, and a wave
+// runs until its slowest lane is done.  So each time the lanes meet (before a walk), lanes without work take over
+// pending subtrees of lanes that have some: the donor gives away the SHALLOWEST sibling still on its trail (the
+// biggest piece of work, two bit operations to detach), the thief gets the ray and the subtree root through wave
+// shuffles and traverses it with an empty trail, which keeps it inside that subtree.  Both feed the ray's key in LDS
+// and refresh their pruning bound from it.  No counters are needed: the wave leaves when none of its lanes has work,
+// and then every key is final.
 template <bool FAST, bool SPLIT, bool LEAF_LDS>
-RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray &ray, Best &best, BvhStats &st) {
+RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray &own_ray, bool active, unsigned long long *res,
+                               int *donor_lane, BvhStats &st) {
   extern __shared__ uint4 bvh_lds[];
   const int lds_nodes = p.bvh_lds_nodes;
   const bool iso = FAST && p.bvh_iso != 0;
-  RT_BVH_COUNT(st.rays);
-  // the spheres kept out of the tree, in object order (strict `<`)
-  for (int k = 0; k < s.n_bvh_big; ++k) {
-    const RecRegs r = load_rec(s.bvh_big, k);
-    sphere_scan_test<FAST>(r, ray, best);
-  }
-  const BvhRay br = bvh_ray(s, ray); // the ray in lattice coordinates
-  const float a = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
-  const float inv_a = 1.f / a;
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long lanes_before = (1ull << lane) - 1ull;
 
-  float bt = best.t;
-  int bpos = -1;
+  // the traversal this lane is running: ray, its lattice form, position in the tree, owner's key
+  V3 o = own_ray.o, d = own_ray.d;
+  float tmin = own_ray.tmin;
+  BvhRay br = bvh_ray(s, own_ray);
+  float a = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
+  float inv_a = 1.f / a;
+  int owner = lane;
+  float bt = INF_F;
   int n = 1, level = 0;
   uint32_t trail = 0; // bit L: the sibling of this path's node at level L is still to be visited
   uint4 cur = bvh_fetch<SPLIT>(s, lds_nodes, 1);
   float tn;
-  bool valid = bvh_box_hit(cur, br, bt, tn);
-  // "while-while": every lane first walks (down, or back up through `trail`) until it sits on a leaf or is done —
-  // LDS reads only —, then the lanes that reached a leaf test its spheres together, so the long-latency sphere loads
-  // are paid once per leaf visit of the slowest lane, not once per step.
-  for (;;) {
-    while (!(valid && cur.w)) {
+  bool valid = active && bvh_box_hit(cur, br, bt, tn);
+  bool alive = valid;  // has a node to process or a trail to follow
+  bool shared = false; // other lanes work on the same ray: bt must be refreshed from the key
+  res[lane] = BVH_NO_HIT;
+  if (active)
+    RT_BVH_COUNT(st.rays);
+
+  while (__any(alive)) {
+    // ---- lanes without work take over pending subtrees ----------------------------------------------------------
+    {
+      const unsigned long long idle_m = __ballot(!alive), donor_m = __ballot(alive && trail != 0u);
+      const int n_pairs = min(__popcll(idle_m), __popcll(donor_m));
+      if (n_pairs > 0) {
+        const int idle_rank = __popcll(idle_m & lanes_before), donor_rank = __popcll(donor_m & lanes_before);
+        const bool is_donor = alive && trail != 0u && donor_rank < n_pairs;
+        const bool is_thief = !alive && idle_rank < n_pairs;
+        int give_node = 0, give_level = 0;
+        if (is_donor) {
+          give_level = __ffs((int)trail) - 1; // the shallowest pending level
+          trail &= trail - 1u;
+          give_node = (n >> (level - give_level)) ^ 1;
+          shared = true;
+          donor_lane[donor_rank] = lane;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // LDS is in order within a wave; this pins the compiler
+        __builtin_amdgcn_wave_barrier();
+        const int src = is_thief ? *reinterpret_cast<volatile int *>(donor_lane + idle_rank) : lane;
+        const int g_node = __shfl(give_node, src, 64), g_level = __shfl(give_level, src, 64), g_owner = __shfl(owner, src, 64);
+        const float g_bt = __shfl(bt, src, 64), g_tmin = __shfl(tmin, src, 64), g_a = __shfl(a, src, 64), g_inv_a = __shfl(inv_a, src, 64);
+        const V3 g_o = mk3(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+        const V3 g_d = mk3(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+        const V3 g_id = mk3(__shfl(br.id.x, src, 64), __shfl(br.id.y, src, 64), __shfl(br.id.z, src, 64));
+        const V3 g_nc = mk3(__shfl(br.nc.x, src, 64), __shfl(br.nc.y, src, 64), __shfl(br.nc.z, src, 64));
+        if (is_thief) {
+          RT_BVH_COUNT(st.steals);
+          o = g_o, d = g_d, tmin = g_tmin, a = g_a, inv_a = g_inv_a;
+          br.id = g_id, br.nc = g_nc;
+          br.rx = (int)((__float_as_uint(g_id.x) >> 31) << 4);
+          br.ry = (int)((__float_as_uint(g_id.y) >> 31) << 4);
+          br.rz = (int)((__float_as_uint(g_id.z) >> 31) << 4);
+          owner = g_owner;
+          bt = g_bt;
+          n = g_node, level = g_level, trail = 0u;
+          cur = bvh_fetch<SPLIT>(s, lds_nodes, n);
+          valid = bvh_box_hit(cur, br, bt, tn);
+          alive = valid;
+          shared = true;
+        }
+      }
+    }
+    if (alive && shared)
+      bt = fminf(bt, __uint_as_float((uint32_t)(*reinterpret_cast<volatile unsigned long long *>(res + owner) >> 32)));
+
+    // ---- walk ----------------------------------------------------------------------------------------------------
+    while (alive && !(valid && cur.w)) {
 #ifdef RT_BVH_STATS
-      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) // first active lane
+      if (lane == __ffsll((long long)__ballot(1)) - 1) // first active lane
         st.wave_iters += 64;
 #endif
       if (valid) { // inner node: both children, nearer one first
@@ -173,8 +252,10 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
         }
       }
       if (!valid) {
-        if (!trail)
+        if (!trail) {
+          alive = false;
           break;
+        }
         RT_BVH_COUNT(st.pop);
         const int L = 31 - __clz((int)trail); // the deepest pending level
         trail ^= 1u << L;
@@ -184,71 +265,72 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
         valid = bvh_box_hit(cur, br, bt, tn); // bt may have shrunk since the bit was set
       }
     }
-    if (!valid)
-      break;
-    RT_BVH_COUNT(st.leaf);
+
+    // ---- leaves --------------------------------------------------------------------------------------------------
+    if (alive) { // valid && cur.w
+      RT_BVH_COUNT(st.leaf);
 #ifdef RT_BVH_STATS
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
-      st.wave_leaf_iters += 64;
+      if (lane == __ffsll((long long)__ballot(1)) - 1)
+        st.wave_leaf_iters += 64;
 #endif
-    const int first = (int)(cur.w & 0xffffffu), count = (int)(cur.w >> 24);
-    if (iso) {
-      // all discriminants as one straight-line block, then one trip per sphere actually hit (mostly one)
-      float disc[BVH_LEAF_MAX], b[BVH_LEAF_MAX];
-      float4 c[BVH_LEAF_MAX];
+      const int first = (int)(cur.w & 0xffffffu), count = (int)(cur.w >> 24);
+      unsigned long long *slot = res + owner;
+      if (iso) {
+        // all discriminants as one straight-line block, then one trip per sphere actually hit (mostly one)
+        float disc[BVH_LEAF_MAX], b[BVH_LEAF_MAX];
+        float4 c[BVH_LEAF_MAX];
 #pragma unroll
-      for (int k = 0; k < BVH_LEAF_MAX; ++k) { // a short leaf tests its last sphere again: harmless
-        const int pos = first + min(k, count - 1);
-        c[k] = LEAF_LDS ? reinterpret_cast<const float4 *>(bvh_lds + lds_nodes)[pos] : reinterpret_cast<const float4 *>(s.bvh_iso)[pos];
-      }
-      uint32_t hits = 0;
-#pragma unroll
-      for (int k = 0; k < BVH_LEAF_MAX; ++k) {
-        const float ocx = ray.o.x - c[k].x, ocy = ray.o.y - c[k].y, ocz = ray.o.z - c[k].z;
-        b[k] = fmaf(ocx, ray.d.x, fmaf(ocy, ray.d.y, ocz * ray.d.z));
-        const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -c[k].w)));
-        disc[k] = fmaf(b[k], b[k], -(a * cc));
-        hits |= (disc[k] > 0.f ? 1u : 0u) << k;
-      }
-      while (hits) {
-        const int k = __ffs((int)hits) - 1;
-        hits &= hits - 1;
-        float dk = disc[0], bk = b[0];
-#pragma unroll
-        for (int j = 1; j < BVH_LEAF_MAX; ++j)
-          if (k == j)
-            dk = disc[j], bk = b[j];
-        const float sq = sqrtf(dk);
-        const float t1 = (-bk - sq) * inv_a, t2 = (-bk + sq) * inv_a;
-        float t = t1;
-        bool ok = true;
-        if (t1 < ray.tmin) {
-          t = t2;
-          ok = t2 > ray.tmin && t2 < ray.tmax;
+        for (int k = 0; k < BVH_LEAF_MAX; ++k) { // a short leaf tests its last sphere again: harmless
+          const int pos = first + min(k, count - 1);
+          c[k] = LEAF_LDS ? reinterpret_cast<const float4 *>(bvh_lds + lds_nodes)[pos] : reinterpret_cast<const float4 *>(s.bvh_iso)[pos];
         }
-        if (ok)
-          bvh_accept(s, first + min(k, count - 1), t, bt, bpos, best.object);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int k = 0; k < BVH_LEAF_MAX; ++k) {
+          const float ocx = o.x - c[k].x, ocy = o.y - c[k].y, ocz = o.z - c[k].z;
+          b[k] = fmaf(ocx, d.x, fmaf(ocy, d.y, ocz * d.z));
+          const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -c[k].w)));
+          disc[k] = fmaf(b[k], b[k], -(a * cc));
+          hits |= (disc[k] > 0.f ? 1u : 0u) << k;
+        }
+        while (hits) {
+          const int k = __ffs((int)hits) - 1;
+          hits &= hits - 1;
+          float dk = disc[0], bk = b[0];
+#pragma unroll
+          for (int j = 1; j < BVH_LEAF_MAX; ++j)
+            if (k == j)
+              dk = disc[j], bk = b[j];
+          const float sq = sqrtf(dk);
+          const float t1 = (-bk - sq) * inv_a, t2 = (-bk + sq) * inv_a;
+          float t = t1;
+          bool ok = true;
+          if (t1 < tmin) {
+            t = t2;
+            ok = t2 > tmin; // tmax = inf for every ray of the path kernels
+          }
+          if (ok && t <= bt)
+            bvh_accept(s, slot, first + min(k, count - 1), t, bt);
+        }
+      } else {
+        Ray ray;
+        ray.o = o, ray.d = d, ray.tmin = tmin, ray.tmax = INF_F;
+        for (int k = 0; k < count; ++k) {
+          float t;
+          const bool hit = FAST ? bvh_gen_front_t(s.bvh_recs[first + k].inv, ray, t) : sphere_front_t(s.bvh_recs[first + k].inv, ray, t);
+          if (hit && t <= bt)
+            bvh_accept(s, slot, first + k, t, bt);
+        }
       }
-    } else {
-      for (int k = 0; k < count; ++k) {
-        float t;
-        const bool hit = FAST ? bvh_gen_front_t(s.bvh_recs[first + k].inv, ray, t) : sphere_front_t(s.bvh_recs[first + k].inv, ray, t);
-        if (hit)
-          bvh_accept(s, first + k, t, bt, bpos, best.object);
-      }
+      valid = false;
+      alive = trail != 0u;
     }
-    valid = false;
-  }
-  if (bpos >= 0) {
-    const int2 ids = *reinterpret_cast<const int2 *>(&s.bvh_recs[bpos].object); // {object, shape}
-    best.t = bt;
-    best.object = ids.x;
-    best.shape = ids.y;
   }
 }
 
 // The small-world path kernel (rt_kernels.h) with the sphere scan replaced; T lanes share one staged copy of the tree
-// (or of its top levels).
+// (or of its top levels).  Dynamic LDS, in uint4 units:
+//   [lds_nodes heap slots] [lds_spheres leaf spheres] [T / 2: one key per ray] [T / 4: donor lanes, 64 per wave]
 template <bool FAST, int T, bool SPLIT, bool LEAF_LDS>
 __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams p) {
   extern __shared__ uint4 bvh_lds[];
@@ -258,10 +340,14 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
   if (LEAF_LDS)
     for (int i = threadIdx.x; i < p.bvh_lds_spheres; i += T)
       bvh_lds[p.bvh_lds_nodes + i] = reinterpret_cast<const uint4 *>(s.bvh_iso)[i];
+  const int wave = (int)(threadIdx.x >> 6);
+  unsigned long long *const res = reinterpret_cast<unsigned long long *>(bvh_lds + p.bvh_lds_nodes + p.bvh_lds_spheres) + 64 * wave;
+  int *const donor_lane = reinterpret_cast<int *>(bvh_lds + p.bvh_lds_nodes + p.bvh_lds_spheres + T / 2) + 64 * wave;
   PathBlock<T, FAST> B;
   B.init(p, sh); // synchronises the workgroup
   BvhStats st{};
   while (B.deal(s, p, sh)) {
+    bvh_closest_sphere<FAST, SPLIT, LEAF_LDS>(s, p, B.ray, B.active, res, donor_lane, st);
     Hit h;
     h.object = h.shape = -1;
     h.t = 0.f;
@@ -271,7 +357,24 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
       best.t = INF_F;
       best.object = 0x7fffffff;
       best.shape = -1;
-      bvh_closest_sphere<FAST, SPLIT, LEAF_LDS>(s, p, B.ray, best, st);
+      const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(res + (threadIdx.x & 63));
+      if ((int)(uint32_t)key >= 0) {
+        const int2 ids = *reinterpret_cast<const int2 *>(&s.bvh_recs[(int)(uint32_t)key].object); // {object, shape}
+        best.t = __uint_as_float((uint32_t)(key >> 32));
+        best.object = ids.x;
+        best.shape = ids.y;
+      }
+      // the spheres kept out of the tree, in object order
+      for (int k = 0; k < s.n_bvh_big; ++k) {
+        const RecRegs rec = load_rec(s.bvh_big, k);
+        Best one;
+        one.t = INF_F;
+        one.object = 0x7fffffff;
+        one.shape = -1;
+        sphere_scan_test<FAST>(rec, B.ray, one);
+        if (one.shape >= 0 && (one.t < best.t || (one.t == best.t && one.object < best.object)))
+          best = one;
+      }
       h = world_finish_hit<FAST>(s, B.ray, best);
     }
     B.shade(s, p, sh, h);
@@ -284,6 +387,7 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
   wave_add_counter(p.counters + 7, st.wave_iters);
   wave_add_counter(p.counters + 8, st.rays);
   wave_add_counter(p.counters + 9, st.wave_leaf_iters);
+  wave_add_counter(p.counters + 10, st.steals);
 #endif
 }
 
