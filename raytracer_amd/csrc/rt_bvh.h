@@ -13,7 +13,9 @@
 //     tree, every level of it for up to ~8000 spheres — staged in LDS: a divergent 16-byte LDS read costs a few
 //     cycles per wave where the same read through the vector memory path costs one cache-line lookup per lane;
 //   * both children of a node are fetched and tested together (adjacent slots), the nearer one is entered first;
-//   * leaves hold up to BVH_LEAF_MAX spheres, regrouped by leaf (bvh_recs / bvh_iso), tested as one straight-line block.
+//   * leaves hold up to BVH_LEAF_MAX spheres, regrouped by leaf (bvh_recs / bvh_iso), tested as one straight-line block;
+//   * lanes of a wave that run out of work take over pending subtrees of the lanes that still have some
+//     (bvh_closest_sphere).
 #pragma once
 #include "rt_path.h"
 
