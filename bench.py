@@ -50,7 +50,7 @@ def pmc_traffic(args):
     launches, each in its own rocprofv3 --pmc pass).  FETCH_SIZE is taken as reported (gfx950 tallies 64 B per 128-B
     request for wide streaming reads; the node-stack reads here are dword gathers, uncalibrated).  None for any other
     configuration: counters cannot be read from inside the timed run."""
-    default = (args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
+    default = (not args.bvh and args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
                and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
     path = os.path.join(ROOT, "profiles", "r1", "g_n512_pmc.json")
     if not default or not os.path.exists(path):
@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=96)
     ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=54)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", action="store_true",
+                    help="RT_FLAG_ACCEL_BVH: not the reference's algorithmic work, so the line carries no roofline fraction")
     ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices, gather staged through the host)")
@@ -143,7 +145,7 @@ def main():
         scene, text = synthetic_scene(args.spheres)
     world = DeviceWorld(scene, dev_index)
     tracer = GpuImageTracer(args.width, args.height, scene.camera, args.aa)
-    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54)
+    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh)
     rows = rank_rows(args.height, rank, world_size)
     local = torch.empty((rows.n_local_rows, args.width, 3), dtype=torch.float32, device=device)
     full = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
@@ -230,7 +232,7 @@ def main():
             "config": {"workload": (f"samples/{args.scene} (reference sample scene)" if args.scene else
                                     f"synthetic {args.spheres}-random-sphere + floor + sky scene") + f", --mode path, "
                                    f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "
-                                   f"max-depth={args.max_depth}, seq-number=54",
+                                   f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else ""),
                        "objects": scene.count("n_objects"), "samples_per_frame": samples_total, "rays_per_frame": rays_total,
                        "rays_per_sample": rays_total / max(samples_total, 1),
                        "parallelism": f"rows-cyclic-x{world_size}" if world_size > 1 else "single"},
@@ -244,6 +246,10 @@ def main():
                          "note": "achieved = reference-as-written flops (52 per sphere test); the kernel issues 17 per test "
                                  "(world-space form, FMA), reported as executed_*"},
         }
+        if args.bvh:  # the hierarchy skips most of the tests the brute-force flop count assumes: no fraction of a roofline
+            out["roofline"] = {"bound": "valu", "achieved": None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                               "traffic": None, "kernel": "rtd::k_render_path_bvh", "rays_per_launch": rays_local, "kernel_ms": kernel_ms,
+                               "note": "BVH mode changes the algorithmic work; see DESIGN.md 4.6 for its step counts"}
         import hashlib
         # the assembled frame is bit-identical for any number of ranks: compare this across --gpus runs
         out["frame_sha256"] = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest()
