@@ -354,6 +354,8 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
     h.object = h.shape = -1;
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+    ShadeFetch fetch;
+    fetch.have = false;
     if (B.active) {
       Best best;
       best.t = INF_F;
@@ -377,9 +379,9 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
         if (one.shape >= 0 && (one.t < best.t || (one.t == best.t && one.object < best.object)))
           best = one;
       }
-      h = world_finish_hit<FAST>(s, B.ray, best);
+      h = world_finish_hit<FAST>(s, B.ray, best, &fetch);
     }
-    B.shade(s, p, sh, h);
+    B.shade(s, p, sh, h, &fetch);
   }
   wave_add_counter(p.counters + 1, B.rays);
 #ifdef RT_BVH_STATS

@@ -557,7 +557,16 @@ template <bool FAST> RT_DEV void scan_spheres(const ScanRec *recs, int n, const 
 
 // Second half of World::ray_intersection (shapes.hpp:547-561) once the spheres have been scanned:
 // planes and CSG objects, ties to the lowest object index, full record for the winner only.
-template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best) {
+// The winner's shading record (rt_types.h ShadeRec), fetched in the same round trip as the matrices its hit record needs
+// instead of one trip later by the shading code.
+struct ShadeFetch {
+  float4 r0, r1;
+  bool have;
+};
+
+template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
+  if (fetch)
+    fetch->have = false;
   for (int i = 0; i < s.n_planes; ++i) {
     const RecRegs r = load_rec(s.planes, i);
     float t;
@@ -599,6 +608,11 @@ template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray,
     h.object = best.object;
     h.shape = best.shape;
     h.t = best.t;
+    if (fetch) {
+      const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + best.shape);
+      fetch->r0 = rec[0], fetch->r1 = rec[1];
+      fetch->have = true;
+    }
     if (FAST) {
       make_hit_fast(s, best.shape, ray, best.t, h.point, h.normal, h.local);
     } else {

@@ -276,7 +276,7 @@ template <int T, bool FAST> struct PathBlock {
 
   // PathTracer::operator() steps 2-6 for the node whose closest hit is `h`; pushes the node when it
   // scatters; retires finished samples.  All lanes must call it (it synchronises the workgroup).
-  RT_DEV void shade(const Scene &s, const RenderParams &p, PathShared<T> &sh, const Hit &h) {
+  RT_DEV void shade(const Scene &s, const RenderParams &p, PathShared<T> &sh, const Hit &h, const ShadeFetch *fetch = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     bool push = false;
     V3 vec = mk3(0.f, 0.f, 0.f), weight = vec;
@@ -287,8 +287,13 @@ template <int T, bool FAST> struct PathBlock {
       if (h.object < 0) {
         emitted = mk3(p.background[0], p.background[1], p.background[2]);
       } else {
-        const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + h.shape);
-        const float4 r0 = rec[0], r1 = rec[1];
+        float4 r0, r1;
+        if (fetch && fetch->have) {
+          r0 = fetch->r0, r1 = fetch->r1;
+        } else {
+          const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + h.shape);
+          r0 = rec[0], r1 = rec[1];
+        }
         const uint32_t mflags = __float_as_uint(r0.w);
         V3 reflected = mk3(r0.x, r0.y, r0.z);
         emitted = mk3(r1.x, r1.y, r1.z);
