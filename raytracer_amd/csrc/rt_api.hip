@@ -46,7 +46,7 @@ struct rt_scene {
   int n_cus = 0;
   std::vector<void *> owned;     // scene tables, freed by rt_scene_destroy
   rtd::Scene dev{};              // device pointers
-  unsigned long long *counters = nullptr; // 4 x u64
+  unsigned long long *counters = nullptr; // rtd::COUNTER_WORDS x u64
   DeviceBuffer samples, stack;   // grow-only scratch reused across renders
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -577,7 +577,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.n_lights = static_cast<int32_t>(d->n_lights);
 #undef UP
   void *cnt = nullptr;
-  if (hipMalloc(&cnt, 16 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc(&cnt, rtd::COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed"));
   sc->counters = static_cast<unsigned long long *>(cnt);
   if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
@@ -707,10 +707,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     p.pool = static_cast<float *>(sc->stack.ptr);
   } else {
     const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
-    grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 32));
+    grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 8)); // 8 waves per SIMD, grid-stride
   }
 
-  RT_HIP(hipMemsetAsync(sc->counters, 0, 16 * sizeof(unsigned long long), stream));
+  RT_HIP(hipMemsetAsync(sc->counters, 0, rtd::COUNTER_WORDS * sizeof(unsigned long long), stream));
   if (stats)
     RT_HIP(hipEventRecord(sc->ev0, stream));
   switch (cfg->mode) {
@@ -732,8 +732,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   if (stats) {
     RT_HIP(hipEventRecord(sc->ev1, stream));
     RT_HIP(hipEventSynchronize(sc->ev1));
-    unsigned long long c[16];
+    unsigned long long c[rtd::COUNTER_WORDS];
     RT_HIP(hipMemcpy(c, sc->counters, sizeof c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < rtd::COUNTER_SLOTS; ++k) // the tallies are spread over slots (rt_path.h)
+      c[1] += c[rtd::COUNTER_BASE + 2 * k], c[2] += c[rtd::COUNTER_BASE + 2 * k + 1];
 #ifdef RT_PROFILE_PHASES
     std::fprintf(stderr, "[rt launch] grid=%u block=%u pool_cap=%d\n", grid, block, p.pool_cap);
     if (c[7])

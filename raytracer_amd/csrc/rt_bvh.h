@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
     }
     B.shade(s, p, sh, h, &fetch);
   }
-  wave_add_counter(p.counters + 1, B.rays);
+  wave_add_tally(p.counters, 0, B.rays);
 #ifdef RT_BVH_STATS
   wave_add_counter(p.counters + 4, st.inner);
   wave_add_counter(p.counters + 5, st.leaf);

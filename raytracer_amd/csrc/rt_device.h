@@ -136,10 +136,39 @@ RT_DEV uint64_t mix64(uint64_t z) { // splitmix64 finaliser
 
 // The AA generator is always PCG(42, 54) (ImageTracer ctor quirk, cameras.hpp:178-183); its state
 // after the constructor, advanced by 2k draws, gives sample k's jitter pair (cameras.hpp:232-233).
+// The jump is the product of the affine maps x -> M_i x + P_i of the set bits i of 2k, where (M_i, P_i) is the
+// generator's step applied 2^i times: powers of one map commute, so they are applied to the state in any order, and
+// for this fixed stream they are compile-time constants — one 64-bit multiply-add per set bit instead of the four
+// multiplies per bit of the generic pcg_advance (which was most of the flat / pointlight kernels' arithmetic at AA > 1).
+struct AaJumpTable {
+  uint64_t mult[64], plus[64], state0;
+};
+constexpr AaJumpTable make_aa_jump_table() {
+  AaJumpTable t{};
+  const uint64_t inc = (54ull << 1u) | 1u;
+  uint64_t m = PCG_MULT, c = inc;
+  for (int i = 0; i < 64; ++i) {
+    t.mult[i] = m;
+    t.plus[i] = c;
+    c = (m + 1) * c;
+    m = m * m;
+  }
+  uint64_t st = 0; // pcg_init(42, 54): random.hpp:41-47
+  st = st * PCG_MULT + inc;
+  st += 42ull;
+  st = st * PCG_MULT + inc;
+  t.state0 = st;
+  return t;
+}
 RT_DEV void aa_jitter(uint64_t k, float &u, float &v) {
+  static constexpr AaJumpTable T = make_aa_jump_table();
   Pcg p;
-  pcg_init(p, 42ull, 54ull);
-  pcg_advance(p, 2 * k);
+  p.inc = (54ull << 1u) | 1u;
+  p.state = T.state0;
+  uint64_t n = 2 * k;
+  for (int i = 1; n >> i; ++i) // bit 0 of 2k is clear
+    if ((n >> i) & 1ull)
+      p.state = p.state * T.mult[i] + T.plus[i];
   u = pcg_random_float(p);
   v = pcg_random_float(p);
 }

@@ -82,8 +82,8 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
     out[1] = c.y;
     out[2] = c.z;
   }
-  wave_add_counter(p.counters + 1, rays);
-  wave_add_counter(p.counters + 2, capped);
+  wave_add_tally(p.counters, 0, rays);
+  wave_add_tally(p.counters, 1, capped);
 }
 
 // Path kernel for small worlds: the workgroup's node pool deals one ray per lane (rt_path.h), every lane
@@ -104,7 +104,7 @@ template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS, 5) k_render
       h = world_ray_intersection<FAST>(s, B.ray);
     B.shade(s, p, sh, h);
   }
-  wave_add_counter(p.counters + 1, B.rays);
+  wave_add_tally(p.counters, 0, B.rays);
 }
 
 // ---------------------------------------------------------------------------------------------

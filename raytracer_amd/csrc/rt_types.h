@@ -141,7 +141,7 @@ struct RenderParams {
   uint64_t n_samples;          // n_local_rows * width * spp_edge^2
   uint64_t sample_stride;      // path mode: coprime to n_samples, about 0.618 n_samples (see rt_path.h)
   float *samples_out;          // [n_samples][3] (== framebuffer when spp_edge == 1)
-  unsigned long long *counters; // [0] next sample, [1] rays, [2] capped samples
+  unsigned long long *counters; // [0] next sample; rays and capped samples: spread over slots from COUNTER_BASE (rt_path.h)
   // path mode: one node stack per workgroup in HBM, SoA: word w of node i of block b at
   // pool[(b * NODE_WORDS + w) * pool_cap + i]   (rt_path.h)
   float *pool;

@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
     atomicAdd(p.counters + 8, n_rays_q);
   }
 #endif
-  wave_add_counter(p.counters + 1, L.rays);
+  wave_add_tally(p.counters, 0, L.rays);
 }
 
 } // namespace rtd
