@@ -47,6 +47,7 @@ struct rt_scene {
   std::vector<void *> owned;     // scene tables, freed by rt_scene_destroy
   rtd::Scene dev{};              // device pointers
   unsigned long long *counters = nullptr; // rtd::COUNTER_WORDS x u64
+  int32_t tab[7] = {0, 0, 0, 0, 0, 0, 0}; // table sizes: shapes, materials, pigments, csg leaves / chain steps / nodes / program entries
   DeviceBuffer samples, stack;   // grow-only scratch reused across renders
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -514,6 +515,11 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
   sc->n_cus = prop.multiProcessorCount;
+  {
+    const size_t sizes[7] = {d->n_shapes, d->n_materials, d->n_pigments, cb.leaves.size(), cb.path.size(), d->n_csg_nodes, cb.prog.size()};
+    for (int i = 0; i < 7; ++i)
+      sc->tab[i] = static_cast<int32_t>(std::min<size_t>(sizes[i], 1u << 30));
+  }
 
   rtd::Scene &S = sc->dev;
 #define UP(expr)                                                                                           \
@@ -651,7 +657,15 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   size_t dyn_lds = 0;
   if (cfg->mode == RT_MODE_PATH) {
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
-    path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
+    const int32_t *tab = sc->tab;
+    p.tab_shapes = tab[0], p.tab_materials = tab[1], p.tab_pigments = tab[2], p.tab_csg_leaves = tab[3], p.tab_csg_path = tab[4];
+    p.tab_csg_nodes = tab[5], p.tab_csg_prog = tab[6];
+    using L = rtd::PathLdsLimits;
+    const bool small_tables = tab[0] <= L::SHAPES && tab[1] <= L::MATERIALS && tab[2] <= L::PIGMENTS && tab[3] <= L::CSG_LEAVES &&
+                              tab[4] <= L::CSG_PATH && tab[5] <= L::CSG_NODES && tab[6] <= L::CSG_PROG && sc->dev.n_csg_tops <= L::CSG_TOPS;
+    path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>)
+                        : (small_tables ? reinterpret_cast<const void *>(rtd::k_render_path<true, true>)
+                                        : reinterpret_cast<const void *>(rtd::k_render_path<true>));
     block = rtd::PATH_THREADS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
     if (use_bvh) {

@@ -148,6 +148,8 @@ struct RenderParams {
   int32_t pool_cap;
   // RT_FLAG_ACCEL_BVH: heap slots and leaf spheres staged in LDS; whether leaves use the (centre, r^2) form (rt_bvh.h)
   int32_t bvh_lds_nodes, bvh_lds_spheres, bvh_iso;
+  // sizes of the lookup tables (k_render_path stages them in LDS when they are all small, rt_kernels.h)
+  int32_t tab_shapes, tab_materials, tab_pigments, tab_csg_leaves, tab_csg_path, tab_csg_nodes, tab_csg_prog;
 };
 
 } // namespace rtd
