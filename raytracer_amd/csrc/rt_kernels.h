@@ -88,7 +88,7 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
 
 // Path kernel for small worlds: the workgroup's node pool deals one ray per lane (rt_path.h), every lane
 // scans the (few) objects itself with wave-uniform scalar record loads.  The kernel waits on memory more than it
-// computes (PMC: 60 % of wave cycles parked), so it is built for 5 waves per SIMD (96 VGPRs, 40 bytes of spills):
+// computes (PMC: 60 % of wave cycles parked), so it is built for 5 waves per SIMD (96 VGPRs, 60-110 bytes of spills per lane):
 // measured 4 -> 5 waves: C4 147 -> 130 ms, C3 24.2 -> 22.2 ms; 6 and 8 waves spill too much.
 constexpr int PATH_THREADS = 256;
 // TABLES_LDS (FAST only, small worlds — the limits below, checked by the host): every table the kernel looks things up
