@@ -5,7 +5,8 @@ pigments, several lights, perspective and orthogonal cameras.  Made by RUNNING T
 (oracle/_ref/rt_ref) on scene-DSL text written here:
 
   random_csg_<k>.scene.json   the World/Camera the reference's parser builds from the text, flattened
-  random_csg_images.npz       the reference's own renders: onoff / flat (AA 1, 2) / pointlight / path (serial PCG)
+  random_csg_images.npz       the reference's own renders of scenes 0-5: onoff / flat (AA 1, 2) / pointlight / path (serial PCG)
+  (scenes 6-23 are flattened only: more worlds for the GPU-against-oracle comparison)
 
 Only runnable where /root/reference exists.  Re-run with:  python tests/golden/make_random_csg_golden.py
 """
@@ -23,7 +24,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle_lib import REF_BIN, read_pfm  # noqa: E402
 
-N_SCENES = 6
+N_SCENES = 6    # with the reference's renders
+N_EXTRA = 18    # flattened by the reference's parser only: GPU-against-oracle cases (tests/test_random_csg.py)
 RENDERS = {
     "onoff_96x64_aa1": ["--mode", "onoff", "--width", 96, "--height", 64, "--aa", 1],
     "flat_96x64_aa1": ["--mode", "flat", "--width", 96, "--height", 64, "--aa", 1],
@@ -137,6 +139,11 @@ def main():
             images["%d_%s" % (k, name)] = read_pfm(pfm)
             print(k, name, info)
     np.savez_compressed(os.path.join(HERE, "random_csg_images.npz"), **images)
+    for k in range(N_SCENES, N_SCENES + N_EXTRA):
+        txt = os.path.join(tmp, "random_csg_%d.txt" % k)
+        with open(txt, "w") as f:
+            f.write(scene_text(k))
+        ref("flatten", txt, os.path.join(HERE, "random_csg_%d.scene.json" % k))
 
 
 if __name__ == "__main__":

@@ -118,3 +118,35 @@ def test_gpu_closest_hits_equal_the_oracle_on_secondary_like_rays(k):
     assert np.array_equal(got["point"][hit], want["point"][hit])
     assert np.array_equal(got["normal"][hit], want["normal"][hit])
     np.testing.assert_allclose(got["uv"][hit], want["uv"][hit], rtol=0, atol=1e-6)
+
+
+# ---- scenes 6 .. 23: flattened by the reference's parser, no reference renders; the GPU against the (pinned) oracle ----
+EXTRA = range(N_SCENES, N_SCENES + 18)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", EXTRA)
+def test_gpu_equals_the_oracle_on_more_random_worlds(k):
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    s = scene(k)
+    world = DeviceWorld(s)
+    try:
+        for mode, w, h, aa in [("onoff", 64, 40, 1), ("flat", 64, 40, 2), ("pointlight", 64, 40, 1)]:
+            t = GpuImageTracer(w, h, s.camera, aa)
+            got = t.fire_all_rays(world, RenderMode(mode))
+            want, ostats = O.render(s, O.make_cfg(w, h, mode, spp_edge=aa))
+            assert np.array_equal(got, want), (k, mode, int((got != want).any(axis=-1).sum()))
+            assert int(t.last_stats.rays) == int(ostats.rays)
+        rays = _secondary_like_rays(s, n=3000, seed=k)
+        want = O.trace_rays(s, rays)
+        got = world.ray_intersection(rays)
+        hit = want["object"] >= 0
+        assert np.array_equal(got["object"], want["object"]) and np.array_equal(got["t"][hit], want["t"][hit])
+        assert np.array_equal(got["point"][hit], want["point"][hit]) and np.array_equal(got["normal"][hit], want["normal"][hit])
+        # path mode, fused kernel with its tables in LDS: the estimator's mean
+        kw = dict(n_rays=3, roulette=2, max_depth=3, seq_number=k)
+        want, _ = O.render(s, O.make_cfg(48, 32, "path", spp_edge=2, **kw))
+        fast = GpuImageTracer(48, 32, s.camera, 2).fire_all_rays(world, RenderMode("path", **kw))
+        assert abs(float(fast.mean()) - float(want.mean())) <= 0.03 * float(want.mean())
+    finally:
+        world.close()
