@@ -242,6 +242,20 @@ RT_API void rt_scene_destroy(rt_scene *scene);
 RT_API rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
                     float *rgb_out_device, void *stream, rt_stats *stats);
 
+/* rt_render for callers that cannot allocate device memory — code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which has no device at all).  Same
+ * arguments, same result bit for bit as rt_render, but the call's scratch (tally counters, the sample buffer of
+ * spp_edge > 1, the node stacks of path mode) is carved out of one file-scope device array of
+ * RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call makes no
+ * hipMalloc / hipFree.  Limits: 1024 + width * n_local_rows * spp_edge^2 * 12 bytes (spp_edge > 1 only) + in path mode
+ * at least one node stack per compute unit (13 * 4 * block * max(max_depth, 1) bytes each, block = 256 lanes for small
+ * worlds) must fit; otherwise RT_ERR_INVALID_ARGUMENT with the sizes in rt_last_error() — render fewer rows per
+ * call (band_* fields) or use rt_render.  All calls on one GPU share that GPU's array (whatever the scene handle):
+ * calls that overlap on one GPU race; order them on one stream or synchronise between them. */
+#define RT_NOALLOC_SCRATCH_BYTES (128u * 1024u * 1024u)
+RT_API rt_status rt_render_noalloc(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
+                                   float *rgb_out_device, void *stream, rt_stats *stats);
+
 /* Same, into host memory (allocates a device framebuffer, renders, copies back, synchronises).
  * This is what the C++ adapter for the reference's ImageTracer calls. */
 RT_API rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,

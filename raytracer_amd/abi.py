@@ -23,6 +23,7 @@ RT_FLAG_OBJECT_SPACE_SPHERES = 2
 RT_FLAG_ACCEL_BVH = 4
 RT_MAX_CSG_DEPTH = 8
 RT_MAX_CSG_LEAVES = 32
+RT_NOALLOC_SCRATCH_BYTES = 128 * 1024 * 1024
 
 MODES = {"onoff": RT_MODE_ONOFF, "flat": RT_MODE_FLAT, "pointlight": RT_MODE_POINTLIGHT, "path": RT_MODE_PATH}
 
@@ -104,6 +105,8 @@ PROTOTYPES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.c_void_p,
                             C.POINTER(rt_stats)]),
+    "rt_render_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.c_void_p,
+                                    C.POINTER(rt_stats)]),
     "rt_render_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p,
                                  C.POINTER(rt_stats)]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

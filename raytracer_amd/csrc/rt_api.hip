@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -38,6 +39,60 @@ struct DeviceBuffer {
   void *ptr = nullptr;
   size_t bytes = 0;
 };
+
+// Makes `device` current for the lifetime of the guard and gives the caller's device back afterwards: no entry point
+// leaves the calling thread on another device than it came with.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess)
+      prev = -1;
+    if (prev != device)
+      err = hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0)
+      (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define RT_ON_DEVICE(device)                                                                               \
+  DeviceGuard device_guard_(device);                                                                       \
+  RT_HIP(device_guard_.err)
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// rt_render_noalloc's workspace: a file-scope device array (every GPU the library runs on holds its own copy until the
+// process ends).  In host code the NAME of the array is only a stand-in for the symbol, not a device address: the
+// address on each device is asked for once, with that device current (scratch_on_device), and only that pointer is
+// ever handed to kernels, hipMemsetAsync or copies.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[SCRATCH_MAX_DEVICES] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.
+rt_status scratch_on_device(int device, unsigned char **out) {
+  if (device < 0 || device >= SCRATCH_MAX_DEVICES)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_noalloc: device index beyond the workspace table");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *ptr = nullptr;
+    RT_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr)
+      return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
 
 } // namespace
 
@@ -501,7 +556,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device visible");
   if (device < 0 || device >= n_dev)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: device index out of range");
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   rt_scene *sc = new (std::nothrow) rt_scene();
   if (!sc)
     return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -595,7 +650,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
 void rt_scene_destroy(rt_scene *sc) {
   if (!sc)
     return;
-  (void)hipSetDevice(sc->device);
+  DeviceGuard guard(sc->device);
   for (void *p : sc->owned)
     (void)hipFree(p);
   if (sc->counters) (void)hipFree(sc->counters);
@@ -606,16 +661,30 @@ void rt_scene_destroy(rt_scene *sc) {
   delete sc;
 }
 
-rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device, void *stream_,
-                    rt_stats *stats) {
+} // extern "C"
+
+namespace {
+
+// Where one render keeps what it needs beyond the scene and the framebuffer (tally counters, the sample buffer when
+// spp > 1, the node stacks of path mode): grow-only buffers of the scene handle (rt_render), or a fixed workspace the
+// caller of this function brings (rt_render_noalloc: the file-scope scratch array), in which case nothing is allocated.
+struct Workspace {
+  unsigned char *fixed = nullptr; // device address, 256-byte aligned; nullptr: allocate in the scene handle
+  size_t fixed_bytes = 0;
+};
+constexpr size_t WS_COUNTER_BYTES = 1024; // >= rtd::COUNTER_WORDS * 8, keeps what follows 256-byte aligned
+static_assert(WS_COUNTER_BYTES >= rtd::COUNTER_WORDS * sizeof(unsigned long long), "counter area too small");
+
+rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device, void *stream_,
+                      rt_stats *stats, const Workspace &ws) {
   if (!sc || !cam || !cfg || !rgb_out_device)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
   if (rt_status st = check_cfg(cfg))
     return st;
   if (cam->kind > RT_CAMERA_PERSPECTIVE)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_camera: unknown kind");
-  RT_HIP(hipSetDevice(sc->device));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  size_t ws_used = WS_COUNTER_BYTES; // fixed workspace: [counters | samples | node stacks]
 
   rtd::RenderParams p{};
   std::memcpy(p.cam.fwd, cam->fwd, sizeof p.cam.fwd);
@@ -634,7 +703,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   const uint64_t n_pixels = static_cast<uint64_t>(cfg->n_local_rows) * static_cast<uint64_t>(cfg->width);
   const int spp2 = cfg->spp_edge * cfg->spp_edge;
   p.n_samples = n_pixels * static_cast<uint64_t>(spp2);
-  p.counters = sc->counters;
+  p.counters = ws.fixed ? reinterpret_cast<unsigned long long *>(ws.fixed) : sc->counters;
   p.sample_stride = 1;
   if (p.n_samples > 2 && p.n_samples < (1ull << 31)) { // the product q * stride must fit 64 bits
     uint64_t a = static_cast<uint64_t>(0.6180339887498949 * static_cast<double>(p.n_samples)) | 1ull;
@@ -644,9 +713,19 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   }
 
   if (spp2 > 1) {
-    if (rt_status st = ensure(sc->samples, p.n_samples * 3 * sizeof(float)))
-      return st;
-    p.samples_out = static_cast<float *>(sc->samples.ptr);
+    const size_t bytes = p.n_samples * 3 * sizeof(float);
+    if (ws.fixed) {
+      if (bytes > ws.fixed_bytes - ws_used)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_noalloc: the sample buffer (width * n_local_rows * spp_edge^2 * 12 = " +
+                                                 std::to_string(bytes) + " bytes) does not fit the " + std::to_string(ws.fixed_bytes) +
+                                                 "-byte workspace; render fewer rows per call or use rt_render");
+      p.samples_out = reinterpret_cast<float *>(ws.fixed + ws_used);
+      ws_used += (bytes + 255) & ~static_cast<size_t>(255);
+    } else {
+      if (rt_status st = ensure(sc->samples, bytes))
+        return st;
+      p.samples_out = static_cast<float *>(sc->samples.ptr);
+    }
   } else {
     p.samples_out = rgb_out_device;
   }
@@ -716,15 +795,30 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
     // node stack of each workgroup: at most `block` nodes per depth level (rt_path.h)
     p.pool_cap = static_cast<int32_t>(block) * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
-    if (rt_status st = ensure(sc->stack, static_cast<size_t>(grid) * rtd::NODE_WORDS * static_cast<size_t>(p.pool_cap) * sizeof(float)))
-      return st;
-    p.pool = static_cast<float *>(sc->stack.ptr);
+    const size_t stack_bytes = rtd::NODE_WORDS * static_cast<size_t>(p.pool_cap) * sizeof(float); // per workgroup
+    if (ws.fixed) {
+      // Fewer workgroups than the device could hold is fine for the result (sample values do not depend on which
+      // workgroup traces them), but below one per CU the call would crawl: refuse instead.
+      const size_t fit = (ws.fixed_bytes - ws_used) / stack_bytes;
+      const unsigned floor_grid = std::min<unsigned>(grid, static_cast<unsigned>(sc->n_cus));
+      if (fit < floor_grid)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_noalloc: the node stacks (" + std::to_string(stack_bytes) + " bytes per workgroup x " +
+                                                 std::to_string(floor_grid) + " workgroups) do not fit what the sample buffer leaves of the " +
+                                                 std::to_string(ws.fixed_bytes) + "-byte workspace; lower max_depth or the rows per call, or use rt_render");
+      grid = static_cast<unsigned>(std::min<size_t>(grid, fit));
+      p.pool = reinterpret_cast<float *>(ws.fixed + ws_used);
+      ws_used += static_cast<size_t>(grid) * stack_bytes;
+    } else {
+      if (rt_status st = ensure(sc->stack, static_cast<size_t>(grid) * stack_bytes))
+        return st;
+      p.pool = static_cast<float *>(sc->stack.ptr);
+    }
   } else {
     const uint64_t want = (p.n_samples + BLOCK - 1) / BLOCK;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 8)); // 8 waves per SIMD, grid-stride
   }
 
-  RT_HIP(hipMemsetAsync(sc->counters, 0, rtd::COUNTER_WORDS * sizeof(unsigned long long), stream));
+  RT_HIP(hipMemsetAsync(p.counters, 0, rtd::COUNTER_WORDS * sizeof(unsigned long long), stream));
   if (stats)
     RT_HIP(hipEventRecord(sc->ev0, stream));
   switch (cfg->mode) {
@@ -747,7 +841,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
     RT_HIP(hipEventRecord(sc->ev1, stream));
     RT_HIP(hipEventSynchronize(sc->ev1));
     unsigned long long c[rtd::COUNTER_WORDS];
-    RT_HIP(hipMemcpy(c, sc->counters, sizeof c, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(c, p.counters, sizeof c, hipMemcpyDeviceToHost));
     for (int k = 0; k < rtd::COUNTER_SLOTS; ++k) // the tallies are spread over slots (rt_path.h)
       c[1] += c[rtd::COUNTER_BASE + 2 * k], c[2] += c[rtd::COUNTER_BASE + 2 * k + 1];
 #ifdef RT_PROFILE_PHASES
@@ -772,12 +866,36 @@ rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg
   return RT_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+rt_status rt_render(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device, void *stream,
+                    rt_stats *stats) {
+  if (!sc)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
+  RT_ON_DEVICE(sc->device);
+  return render_impl(sc, cam, cfg, rgb_out_device, stream, stats, Workspace{});
+}
+
+rt_status rt_render_noalloc(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device, void *stream,
+                            rt_stats *stats) {
+  if (!sc)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_noalloc: NULL argument");
+  RT_ON_DEVICE(sc->device);
+  Workspace ws;
+  if (rt_status st = scratch_on_device(sc->device, &ws.fixed))
+    return st;
+  ws.fixed_bytes = RT_NOALLOC_SCRATCH_BYTES;
+  return render_impl(sc, cam, cfg, rgb_out_device, stream, stats, ws);
+}
+
 rt_status rt_render_host(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, rt_stats *stats) {
   if (!sc || !cfg || !rgb_out_host)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_host: NULL argument");
   if (rt_status st = check_cfg(cfg))
     return st;
-  RT_HIP(hipSetDevice(sc->device));
+  RT_ON_DEVICE(sc->device);
   const size_t bytes = static_cast<size_t>(cfg->n_local_rows) * cfg->width * 3 * sizeof(float);
   float *fb = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&fb), bytes));
@@ -796,7 +914,7 @@ rt_status rt_trace_rays(rt_scene *sc, const rt_ray *rays, size_t n, rt_hit *hits
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_rays: NULL argument");
   if (n == 0)
     return RT_OK;
-  RT_HIP(hipSetDevice(sc->device));
+  RT_ON_DEVICE(sc->device);
   rt_ray *d_rays = nullptr;
   rt_hit *d_hits = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_rays), n * sizeof(rt_ray)));
@@ -820,7 +938,7 @@ rt_status rt_offset_if_visible(rt_scene *sc, const float *viewer, const float *s
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_offset_if_visible: NULL argument");
   if (n == 0)
     return RT_OK;
-  RT_HIP(hipSetDevice(sc->device));
+  RT_ON_DEVICE(sc->device);
   float *d_in = nullptr;
   uint8_t *d_out = nullptr;
   const size_t fb = 3 * n * sizeof(float);
@@ -847,7 +965,7 @@ rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_aa_jitter: NULL argument");
   if (n == 0)
     return RT_OK;
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   uint64_t *d_k = nullptr;
   float *d_uv = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_k), n * sizeof(uint64_t)));
@@ -872,7 +990,7 @@ rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const f
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_scatter_rays: bad argument");
   if (n == 0)
     return RT_OK;
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   uint64_t *d_pcg = nullptr;
   float *d_f = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_pcg), 2 * n * sizeof(uint64_t)));
@@ -916,7 +1034,7 @@ rt_status average_luminosity(int device, const float *rgb, size_t n_pixels, floa
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_tonemap: unknown flag");
   if (reinterpret_cast<uintptr_t>(rgb) % 16)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_tonemap: the image must be 16-byte aligned");
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   float cumsum = 0.f;
   const unsigned blocks = static_cast<unsigned>((n_pixels + 255) / 256);
   if (flags & RT_TONEMAP_SERIAL_SUM) {
@@ -974,7 +1092,7 @@ rt_status rt_tonemap(int device, const float *rgb_device, size_t n_pixels, const
   if (!cfg->has_avg_luminosity)
     if (rt_status st = average_luminosity(device, rgb_device, n_pixels, cfg->delta, cfg->flags, stream, &avg))
       return st;
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   const float scale = cfg->alpha / avg; // colors.hpp:485
   const size_t n_comp = 3 * n_pixels, quads = (n_comp + 3) / 4;
   hipLaunchKernelGGL(rtd::k_tonemap, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, rgb_device, n_comp, scale,
@@ -989,7 +1107,7 @@ rt_status rt_tonemap_host(int device, const float *rgb_host, size_t n_pixels, co
                           float *avg_used_out) {
   if (!rgb_host || !cfg || !ldr_out_host || n_pixels == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_tonemap_host: NULL argument or empty image");
-  RT_HIP(hipSetDevice(device));
+  RT_ON_DEVICE(device);
   float *rgb = nullptr;
   uint8_t *ldr = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&rgb), 3 * n_pixels * sizeof(float)));
