@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — path-mode throughput of the MI355X tracing backend on the synthetic N-sphere scene.
+"""bench.py — path-mode throughput of the MI355X tracing backend.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" = one full frame of BASELINE.json's metric: --mode path, 1920x1080, AA=4 (16 spp), n_rays=10,
-roulette=3, max-depth=5, on the synthetic N-random-sphere + floor + sky scene of raytracer_amd/synth.py.
-Default N = 512: 3.1e10 rays per frame (927 per sample), about 7 s on one MI355X.  The 4096-sphere scene of
-BASELINE configs[4] is the same generator with --spheres 4096; its 1080p frame is 3.9e11 rays x 4098 sphere
-tests = 1.6e15 tests, minutes per frame on one GPU, so it is run explicitly (DESIGN.md has the numbers).
-With N ranks the frame's rows are dealt round-robin row by row (strong scaling: the frame is fixed), each rank
-renders its bands into HBM and rank 0 gathers them over RCCL.  The scene and the framebuffers are resident in
-HBM before the timed region.  A ray = one World::ray_intersection query (closest hit over every object).
+A "step" = one full frame of BASELINE.json's metric: --mode path, 1920x1080, AA=4 (16 spp), n_rays=10, roulette=3,
+max-depth=5, on the synthetic N-random-sphere + floor + sky scene of raytracer_amd/synth.py.  Default N = 512:
+3.1e10 rays per frame, about 5 s on one MI355X.  Every object is tested for every ray (World::ray_intersection is a
+linear scan, reference include/shapes.hpp:547-561); a ray = one such closest-hit query.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (a child
+`python -m torch.distributed.run`, decided before anything touches the GPU) and relays rank 0's line.  The frame's rows
+are dealt round-robin row by row (strong scaling: the frame is fixed), each rank renders its bands into HBM and rank 0
+gathers them over RCCL.  Scene and framebuffers are resident in HBM before the timed region.
+
+At N = 1 the line also carries `configs`: every BASELINE.json config measured in the same run — C1 (onoff), C2 (flat and
+pointlight), C3, C4 (path on the reference's sample scenes, full size) and C5, the 4096-sphere scene, as ONE 1/16
+row-cyclic slice of its 1920x1080 AA=4 frame (exactly one rank's share of a 16-GPU run; a whole frame is 16 of them,
+~7 minutes on one GPU) — each with its kernel, ray count, kernel ms (HIP events of the same launch) and roofline block.
+
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -29,35 +36,69 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md)
 
+# fp32 flops one object test costs (FMA = 2, everything else 1), by the arithmetic form a kernel uses:
+#   world-space sphere (wide ISO register rows): oc = O - C (3), b = oc.D (5), c = oc.oc - r^2 (6), disc = b^2 - a c (3)
+#   object-space sphere, FMA form (sphere_scan_test<true>): D' = M D (15), O' = M O + t (18), a (5), b (5), c (6), disc (3)
+#   object-space sphere as the reference writes it (and the exact kernels execute it): 33 + 19
+#   plane, FMA form: z row only (6 + 5) + t (2); as written: 33 + 2
+F_SPHERE_WORLD, F_SPHERE_OBJECT, F_SPHERE_WRITTEN = 17.0, 52.0, 52.0
+F_PLANE_FMA, F_PLANE_WRITTEN = 13.0, 35.0
+F_EPILOGUE = 54.0 + 75.0  # the winner's hit record + scatter / shading, same in both counts
 
-def executed_flops_per_ray(n_spheres_top: int, n_planes_top: int, iso: bool) -> float:
-    """fp32 flops the wide kernel actually issues per ray (FMA = 2): the world-space sphere test is
-    3 sub + 5 (b) + 6 (c) + 3 (disc) = 17, the object-space form 2*27 - 3 = 51; plus the same epilogue."""
-    return (17.0 if iso else 51.0) * n_spheres_top + 35.0 * n_planes_top + 54.0 + 75.0
+
+def scene_census(scene):
+    import numpy as np
+    top = scene.objects[scene.objects >= 0]
+    n_sph = int(np.sum(scene.shape_kind[top] == 0))
+    return {"spheres": n_sph, "planes": int(len(top)) - n_sph, "csg": int(np.sum(scene.objects < 0))}
 
 
-def flops_per_ray(n_spheres_top: int, n_planes_top: int) -> float:
-    """Algorithmic fp32 flops of one closest-hit query + shading, counted on the reference's arithmetic as
-    written: 52 per sphere test that misses (33 ray->object frame + 19 up to the discriminant),
-    +7 for a sphere that is hit (the sky sphere always is), 35 per plane, 54 for the winner's hit record,
-    ~75 for scatter + shading."""
-    return 52.0 * n_spheres_top + 7.0 + 35.0 * n_planes_top + 54.0 + 75.0
+def flops_per_ray(census, kernel: str):
+    """-> (executed, algorithmic) fp32 flops of one closest-hit query + shading.  `algorithmic` is the reference's
+    arithmetic as written (52 per sphere test, +7 for the one sphere that is hit, 35 per plane); `executed` is what the
+    kernel named in rt_stats.kernel issues.  CSG trees are not counted in either: a lower bound where a scene has one."""
+    n_sph, n_pl = census["spheres"], census["planes"]
+    algorithmic = F_SPHERE_WRITTEN * n_sph + 7.0 + F_PLANE_WRITTEN * n_pl + F_EPILOGUE
+    if "wide<ISO" in kernel:  # register rows in the world-space form; the big (sky) sphere is scanned per lane
+        executed = F_SPHERE_WORLD * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE
+    elif "EXACT" in kernel or "simple" in kernel:  # unfused, the reference's operation order
+        executed = algorithmic
+    else:  # k_render_path<FMA...>, wide<GEN>: object-space FMA form
+        executed = F_SPHERE_OBJECT * n_sph + F_PLANE_FMA * n_pl + F_EPILOGUE
+    return executed, algorithmic
+
+
+def roofline_block(census, kernel, rays, kernel_ms, traffic=None, bvh=False):
+    if bvh:  # the hierarchy skips most of the tests a brute-force flop count assumes: no fraction of a roofline
+        return {"bound": "valu", "achieved": None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms,
+                "note": "BVH mode changes the algorithmic work; see DESIGN.md 4.6 for its step counts"}
+    executed, algorithmic = flops_per_ray(census, kernel)
+    ach = rays * executed / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "valu", "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
+            "traffic": traffic, "kernel": kernel, "flops_per_ray": executed, "rays_per_launch": rays, "kernel_ms": kernel_ms,
+            "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": rays * algorithmic / (kernel_ms * 1e-3) / 1e12,
+            "note": "achieved / frac count the flops the kernel issues (FMA = 2); algorithmic_* count the reference's arithmetic "
+                    "as written for the same rays (52 flops per sphere test) and may exceed the peak"}
 
 
 def pmc_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel from the committed counter passes of THIS configuration
-    (scripts/pmc_run.sh -> profiles/r1/g_n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the run's two
-    launches, each in its own rocprofv3 --pmc pass).  FETCH_SIZE is taken as reported (gfx950 tallies 64 B per 128-B
-    request for wide streaming reads; the node-stack reads here are dword gathers, uncalibrated).  None for any other
-    configuration: counters cannot be read from inside the timed run."""
+    """HBM-side bytes per launch of the dominant kernel, from the committed counter passes of THIS configuration
+    (scripts/pmc_run.sh -> profiles/r2/n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, each in its own rocprofv3 --pmc
+    pass, summed over the launches of one run and divided by their number).  None for any other configuration:
+    counters cannot be read from inside the timed run."""
     default = (not args.bvh and args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
                and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
-    path = os.path.join(ROOT, "profiles", "r1", "g_n512_pmc.json")
-    if not default or not os.path.exists(path):
+    if not default:
         return None
-    with open(path) as f:
-        c = json.load(f)["counters"]
-    return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / 2.0
+    for rel in (("profiles", "r2", "n512_pmc.json"), ("profiles", "r1", "g_n512_pmc.json")):
+        path = os.path.join(ROOT, *rel)
+        if os.path.exists(path):
+            with open(path) as f:
+                j = json.load(f)
+            c = j["counters"]
+            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / float(j.get("launches", 2))
+    return None
 
 
 def cpu_baseline(scene, text, args):
@@ -92,6 +133,69 @@ def cpu_baseline(scene, text, args):
     return out
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a fresh child (this process has not touched the GPU and
+    never will) and pass rank 0's output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def measure_configs(device, log):
+    """BASELINE.json's five configs, each as one sub-record (N = 1 only).  Times are HIP events around the very launch
+    whose ray count is reported (rt_stats of the same call); C1-C4: best of 3 after one warm-up launch."""
+    import torch
+    from raytracer_amd.scene import FlatScene
+    from raytracer_amd.synth import synthetic_scene
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode, RowBands
+    golden = os.path.join(ROOT, "tests", "golden")
+    recs = []
+
+    def run(cid, label, scene, mode, w, h, aa, rows=None, reps=3, note=None):
+        world = DeviceWorld(scene, device.index)
+        tracer = GpuImageTracer(w, h, scene.camera, aa)
+        rows = rows or RowBands.whole(h)
+        out = torch.empty((rows.n_local_rows, w, 3), dtype=torch.float32, device=device)
+        best, st = None, None
+        for k in range(reps + (1 if reps > 1 else 0)):  # reps > 1: the first launch is a warm-up
+            tracer.fire_all_rays(world, mode, rows, out=out, want_stats=True)
+            if (reps == 1 or k > 0) and (best is None or tracer.last_stats.kernel_ms < best):
+                best, st = float(tracer.last_stats.kernel_ms), tracer.last_stats
+        kernel = st.kernel.decode()
+        rec = {"id": cid, "workload": label, "objects": scene.count("n_objects"), "kernel": kernel, "grid": int(st.grid), "block": int(st.block),
+               "samples": int(st.samples), "rays": int(st.rays), "capped_samples": int(st.capped_samples), "kernel_ms": best,
+               "Mrays_per_s": st.rays / best / 1e3,
+               "roofline": roofline_block(scene_census(scene), kernel, int(st.rays), best)}
+        if note:
+            rec["note"] = note
+        world.close()
+        recs.append(rec)
+        log(f"{cid}: {best:.3f} ms, {rec['Mrays_per_s']:.0f} Mrays/s, {kernel}")
+
+    onoff = FlatScene.from_json(os.path.join(golden, "demo_onoff.scene.json"))
+    demo = FlatScene.from_json(os.path.join(golden, "demo_path.scene.json"))
+    csg = FlatScene.from_json(os.path.join(golden, "csg_example.scene.json"))
+    run("C1", "samples/demo_onoff_tracing.txt, --mode onoff, 1280x960, AA=1", onoff, RenderMode("onoff"), 1280, 960, 1)
+    run("C2-flat", "samples/demo_path_tracing.txt, --mode flat, 1280x960, AA=2", demo, RenderMode("flat"), 1280, 960, 2)
+    run("C2-pointlight", "samples/demo_path_tracing.txt, --mode pointlight, 1280x960, AA=2", demo, RenderMode("pointlight"), 1280, 960, 2)
+    run("C3", "samples/demo_path_tracing.txt, --mode path 10/3/5, 1280x960, AA=2", demo, RenderMode("path"), 1280, 960, 2)
+    run("C4", "samples/csg_example.txt, --mode path 10/3/5, 1920x1080, AA=4", csg, RenderMode("path"), 1920, 1080, 4,
+        note="roofline counts the two top-level objects only (the CSG tree's leaf and inside tests are not counted): a lower bound")
+    big = synthetic_scene(4096)[0]
+    run("C5-slice", "synthetic 4096-random-sphere + floor + sky, --mode path 10/3/5, 1920x1080, AA=4: rows 0, 16, 32, ... "
+        "(one 1/16 row-cyclic slice = one rank's share of 16; a whole frame is 16 such launches)", big, RenderMode("path"), 1920, 1080, 4,
+        rows=RowBands.cyclic(1080, 0, 16, band_rows=1), reps=1,
+        note="whole-frame estimate = 16 x kernel_ms (slices differ by < 1 %, profiles/r1/h_full_n4096_1080p_aa4.json); "
+             "configs[4]'s 3840x2160 frame is 64 slices of this cost")
+    recs[-1]["frame_ms_estimate_one_gpu"] = 16.0 * recs[-1]["kernel_ms"]
+    return recs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,12 +213,16 @@ def main():
     ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=96)
     ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=54)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1-C5) of the N=1 line")
     ap.add_argument("--bvh", action="store_true",
                     help="RT_FLAG_ACCEL_BVH: not the reference's algorithmic work, so the line carries no roofline fraction")
     ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices, gather staged through the host)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -161,10 +269,6 @@ def main():
         if staged and rank == 0:
             full.copy_(full_g)
 
-    def step(want_stats=False):
-        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=want_stats)
-        gather()
-
     def barrier():
         if world_size > 1:
             dist.barrier()
@@ -174,13 +278,17 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     log(f"scene uploaded: {scene.count('n_objects')} objects; frame {args.width}x{args.height} AA={args.aa}")
-    # One stats pass (untimed): the ray count of a frame is deterministic (streams depend only on the sample index)
-    step(want_stats=True)
-    rays_local = int(tracer.last_stats.rays)
-    samples_local = int(tracer.last_stats.samples)
-    log(f"stats pass: {rays_local} rays, {samples_local} samples, kernel {tracer.last_stats.kernel_ms:.1f} ms")
+    # Warm-up.  The first pass also reads the launch's statistics: the ray count of a frame is deterministic (streams
+    # depend only on the sample index), so it holds for every timed step.
+    tracer.fire_all_rays(world, mode, rows, out=local, want_stats=True)
+    gather()
+    st = tracer.last_stats
+    rays_local, samples_local = int(st.rays), int(st.samples)
+    kernel_name = st.kernel.decode() if rows.n_local_rows else ""
+    log(f"stats pass: {rays_local} rays, {samples_local} samples, kernel {st.kernel_ms:.1f} ms, {kernel_name} grid {st.grid} x {st.block}")
     for _ in range(max(args.warmup - 1, 0)):
-        step()
+        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
+        gather()
     torch.cuda.synchronize()
     barrier()
 
@@ -213,14 +321,7 @@ def main():
     rays_total, samples_total = int(r[0]), int(r[1])
 
     if rank == 0:
-        import numpy as np
-        top_shapes = scene.objects[scene.objects >= 0]
-        n_sph_top = int(np.sum(scene.shape_kind[top_shapes] == 0))  # RT_SHAPE_SPHERE; the sky sphere is one of them
-        n_pl_top = int(len(top_shapes)) - n_sph_top
-        f_ray = flops_per_ray(n_sph_top, n_pl_top)  # CSG trees are not counted: a lower bound for scenes that have them
-        # dominant kernel = k_render_path on rank 0's share; achieved = algorithmic flops of ITS rays / ITS duration
-        achieved = rays_local * f_ray / (kernel_ms * 1e-3) / 1e12
-        executed = rays_local * executed_flops_per_ray(n_sph_top, n_pl_top, True) / (kernel_ms * 1e-3) / 1e12
+        census = scene_census(scene)
         out = {
             "metric": "path-mode Mrays/s (frame ms in ms_per_step), 1920x1080 AA=4",
             "value": rays_total * args.steps / elapsed / 1e6,
@@ -233,36 +334,30 @@ def main():
                                     f"synthetic {args.spheres}-random-sphere + floor + sky scene") + f", --mode path, "
                                    f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "
                                    f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else ""),
-                       "objects": scene.count("n_objects"), "samples_per_frame": samples_total, "rays_per_frame": rays_total,
-                       "rays_per_sample": rays_total / max(samples_total, 1),
+                       "objects": scene.count("n_objects"), "top_level": census, "samples_per_frame": samples_total,
+                       "rays_per_frame": rays_total, "rays_per_sample": rays_total / max(samples_total, 1),
                        "parallelism": f"rows-cyclic-x{world_size}" if world_size > 1 else "single"},
             "kernel_ms_per_step_max_rank": kernel_ms_max,
             "gather_ms_per_step": {"rank0_including_wait_for_slowest_rank": gather_ms, "min_over_ranks": float(g[0])},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": pmc_traffic(args),
-                         "kernel": "rtd::k_render_path_wide<ISO,K,W> (+ k_resolve, <0.1 %)", "flops_per_ray": f_ray,
-                         "rays_per_launch": rays_local, "kernel_ms": kernel_ms,
-                         "executed_tflops": executed, "executed_frac": executed / FP32_VALU_PEAK_TFLOPS,
-                         "note": "achieved = reference-as-written flops (52 per sphere test); the kernel issues 17 per test "
-                                 "(world-space form, FMA), reported as executed_*"},
+            # dominant kernel on rank 0's share: ITS rays / ITS duration (k_resolve rides in the same interval, < 0.1 %)
+            "roofline": roofline_block(census, kernel_name, rays_local, kernel_ms, pmc_traffic(args), bvh=args.bvh),
         }
-        if args.bvh:  # the hierarchy skips most of the tests the brute-force flop count assumes: no fraction of a roofline
-            out["roofline"] = {"bound": "valu", "achieved": None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                               "traffic": None, "kernel": "rtd::k_render_path_bvh", "rays_per_launch": rays_local, "kernel_ms": kernel_ms,
-                               "note": "BVH mode changes the algorithmic work; see DESIGN.md 4.6 for its step counts"}
         import hashlib
         # the assembled frame is bit-identical for any number of ranks: compare this across --gpus runs
         out["frame_sha256"] = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest()
-        if world_size == 1 and not args.no_cpu_baseline:
-            log("timing the CPU baseline on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(scene, text, args)
         if args.save_pfm:
             img = full.cpu().numpy()
             with open(args.save_pfm, "wb") as f:
                 f.write(b"PF\n%d %d\n-1.0\n" % (args.width, args.height))
                 f.write(img[::-1].astype("<f4").tobytes())
-        print(json.dumps(out), flush=True)
     world.close()
+    if rank == 0:
+        if world_size == 1 and not args.no_configs:
+            out["configs"] = measure_configs(device, log)
+        if world_size == 1 and not args.no_cpu_baseline:
+            log("timing the CPU baseline on a bounded sample ...")
+            out["cpu_baseline"] = cpu_baseline(scene, text, args)
+        print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.destroy_process_group()
 

@@ -193,6 +193,9 @@ typedef struct rt_stats {
   uint64_t samples;        /* pixel samples traced                                                */
   uint64_t capped_samples; /* pointlight samples that hit max_mirror_bounces                       */
   float kernel_ms;         /* trace (+ resolve) kernel time from hipEvents; 0 if !timing            */
+  /* which kernel traced the frame and how it was launched (measurement reports name it; the CPU oracle leaves "") */
+  uint32_t grid, block;    /* workgroups, lanes per workgroup                                      */
+  char kernel[48];         /* e.g. "k_render_path_wide<ISO,K=8,W=1>", NUL-terminated               */
 } rt_stats;
 
 /* World::ray_intersection result for rt_trace_rays: HitRecord (include/shapes.hpp:65-96) as POD. */

@@ -751,6 +751,7 @@ RTO_EXPORT int rto_render(const rt_scene_desc *s, const rt_camera *cam, const rt
     }
   }
   if (stats) {
+    memset(stats, 0, sizeof *stats);
     stats->rays = ctx.cnt.rays;
     stats->samples = samples;
     stats->capped_samples = ctx.cnt.capped;

@@ -68,7 +68,7 @@ class rt_render_cfg(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("capped_samples", C.c_uint64),
-                ("kernel_ms", C.c_float)]
+                ("kernel_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32), ("kernel", C.c_char * 48)]
 
 
 class rt_hit(C.Structure):

@@ -733,6 +733,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
   constexpr int BLOCK = 256;
   unsigned grid, block = BLOCK;
   const void *path_kernel = nullptr;
+  char kernel_name[48] = "";
+  static const char *const simple_names[3] = {"k_render_simple<ONOFF>", "k_render_simple<FLAT>", "k_render_simple<POINTLIGHT>"};
+  if (cfg->mode != RT_MODE_PATH)
+    std::snprintf(kernel_name, sizeof kernel_name, "%s", simple_names[cfg->mode]);
   size_t dyn_lds = 0;
   if (cfg->mode == RT_MODE_PATH) {
     const bool exact = (cfg->flags & RT_FLAG_EXACT_ARITHMETIC) != 0;
@@ -745,6 +749,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>)
                         : (small_tables ? reinterpret_cast<const void *>(rtd::k_render_path<true, true>)
                                         : reinterpret_cast<const void *>(rtd::k_render_path<true>));
+    std::snprintf(kernel_name, sizeof kernel_name, "k_render_path<%s>", exact ? "EXACT" : (small_tables ? "FMA,TABLES_LDS" : "FMA"));
     block = rtd::PATH_THREADS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
     if (use_bvh) {
@@ -768,6 +773,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
   (exact ? (split ? RT_BVH_K(false, T, true, false) : RT_BVH_K(false, T, false, false))                           \
          : (split ? RT_BVH_K(true, T, true, false) : (leaf_lds ? RT_BVH_K(true, T, false, true) : RT_BVH_K(true, T, false, false))))
       path_kernel = block == 256 ? RT_BVH_PICK(256) : RT_BVH_PICK(512);
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_bvh<%s,T=%u%s%s>", exact ? "EXACT" : "FMA", block, split ? ",SPLIT" : "",
+                    leaf_lds ? ",LEAF_LDS" : "");
 #undef RT_BVH_PICK
 #undef RT_BVH_K
       dyn_lds = static_cast<size_t>(p.bvh_lds_nodes + p.bvh_lds_spheres) * sizeof(rtd::BvhNode) + 12 * static_cast<size_t>(block);
@@ -787,6 +794,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       const int k = std::min((rows + waves - 1) / waves, kmax);
       block = 64u * static_cast<unsigned>(waves);
       path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wide<%s,K=%d,W=%d>", iso ? "ISO" : "GEN", k, waves);
     }
     int per_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), dyn_lds));
@@ -862,6 +870,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     stats->samples = p.n_samples;
     stats->capped_samples = c[2];
     stats->kernel_ms = ms;
+    stats->grid = grid;
+    stats->block = block;
+    std::memcpy(stats->kernel, kernel_name, sizeof stats->kernel);
   }
   return RT_OK;
 }

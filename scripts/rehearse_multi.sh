@@ -1,12 +1,10 @@
 #!/bin/bash
 # Rehearsal of bench.py's N>1 path on ONE GPU: 1, 2 and 3 ranks sharing device 0 (gloo, host-staged gather).
-# The frame checksum must be the same for every rank count.
+# bench.py --gpus N starts its own ranks (no launcher around it).  The frame checksum must be the same for every rank count.
 set -e
-args="--spheres 128 --width 640 --height 360 --aa 2 --steps 1 --warmup 1 --no-cpu-baseline --backend gloo"
-timeout -k 10 120 python3 bench.py --gpus 1 $args > gpurun_out/rehearse_1.json
-for n in 2 3; do
-  timeout -k 10 180 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29510 + n)) \
-      bench.py --gpus $n $args > gpurun_out/rehearse_$n.json
+args="--spheres 128 --width 640 --height 360 --aa 2 --steps 1 --warmup 1 --no-cpu-baseline --no-configs --backend gloo"
+for n in 1 2 3; do
+  timeout -k 10 180 python3 bench.py --gpus $n $args > gpurun_out/rehearse_$n.json
 done
 python3 - <<'PY'
 import json

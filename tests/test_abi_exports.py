@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
         "rt_camera": ["kind", "fwd", "asp_ratio", "has_asp_ratio", "distance"],
         "rt_render_cfg": ["width", "mode", "seq_number", "background", "ambient", "max_mirror_bounces", "rng_mode",
                           "band_rows", "n_local_rows", "flags"],
-        "rt_stats": ["rays", "samples", "capped_samples", "kernel_ms"],
+        "rt_stats": ["rays", "samples", "capped_samples", "kernel_ms", "grid", "block", "kernel"],
         "rt_hit": ["object", "shape", "t", "point", "normal", "uv"],
         "rt_ray": ["origin", "direction", "tmin", "tmax"],
     }
