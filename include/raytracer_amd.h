@@ -228,7 +228,9 @@ RT_API int rt_device_count(void);
 /* Scene -------------------------------------------------------------------------------------------
  * Replaces: the World the reference hands to build_renderer (src/raytracer.cpp:147) — flattened
  * once, reused for any number of renders (animation frames change only the camera).
- * Validates every index / enum / CSG limit; copies the arrays to `device`. */
+ * Validates every index / enum / CSG limit; copies the arrays to `device`.  The description must be a forest, as the
+ * reference's World is (every Object has one owner): a shape or CSG node referenced twice — by objects[] and / or by
+ * CSG children — is refused with RT_ERR_INVALID_ARGUMENT; list the shape twice instead. */
 RT_API rt_status rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
 RT_API void rt_scene_destroy(rt_scene *scene);
 
@@ -241,6 +243,9 @@ RT_API void rt_scene_destroy(rt_scene *scene);
  *                 local row 0 first (HdrImage::pixels layout for the rows this call owns).
  * stream:         hipStream_t as void* (NULL = default stream).  The call enqueues and returns;
  *                 it synchronises only if `stats` is non-NULL (to read the counters back).
+ * One render in flight per rt_scene: the handle owns the call's scratch (tally counters, sample buffer, node stacks,
+ * timing events), so calls on one handle must be ordered on one stream (or synchronised between); for concurrent
+ * renders of one World create one handle per stream.  The calling thread's current device is left as it was.
  */
 RT_API rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
                     float *rgb_out_device, void *stream, rt_stats *stats);
@@ -282,8 +287,11 @@ RT_API rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n
 /* Batch BRDF::scatter_ray directions: DiffusiveBRDF (include/materials.hpp:199-211, consumes two
  * draws of the given PCG via PCG::random_phong(1), include/random.hpp:75-84) or SpecularBRDF
  * (include/materials.hpp:252-261, consumes none).  pcg: [n][2] = {state, inc} in/out; in_dir,
- * normal, dir_out: [n][3].  Host pointers; parity entry point. */
-RT_API rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const float *in_dir,
+ * normal, dir_out: [n][3].  flags: RT_FLAG_EXACT_ARITHMETIC = the reference's formulas (libm acos / sin / cos,
+ * IEEE divisions), what path mode runs under that flag; 0 = the forms path mode runs by default (reciprocal
+ * square root, cos theta = sqrt(x), sin theta = sqrt(1 - x), hardware sin / cos of phi).  Host pointers; parity
+ * entry point. */
+RT_API rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint32_t flags, uint64_t *pcg, const float *in_dir,
                                  const float *normal, size_t n, float *dir_out);
 
 /* ---------------------------------------------------------------------------------------------

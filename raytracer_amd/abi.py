@@ -112,7 +112,7 @@ PROTOTYPES = {
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_offset_if_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_aa_jitter": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "rt_scatter_rays": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rt_scatter_rays": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_average_luminosity": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]),
     "rt_tonemap": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(rt_tonemap_cfg), C.c_void_p, C.c_void_p, C.c_void_p,
                              C.POINTER(C.c_float)]),

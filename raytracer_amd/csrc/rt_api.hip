@@ -423,6 +423,42 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   for (uint32_t node = 0; node < d->n_csg_nodes; ++node)
     if (!cb.ref_ok(d->csg_left[node], static_cast<int32_t>(node)) || !cb.ref_ok(d->csg_right[node], static_cast<int32_t>(node)))
       return fail(RT_ERR_INVALID_ARGUMENT, "csg child reference out of range (children must precede their parent)");
+  for (uint32_t i = 0; i < d->n_objects; ++i)
+    if (!cb.ref_ok(d->objects[i], static_cast<int32_t>(d->n_csg_nodes)))
+      return fail(RT_ERR_INVALID_ARGUMENT, "objects[] reference out of range");
+  // The World is a forest, as in the reference, where every Object is owned by exactly one unique_ptr (World::objects or
+  // a CSGObject's object1 / object2, include/shapes.hpp:384-385,525): a shape or node referenced twice is refused.  (The
+  // per-shape tables with the CSG ancestors folded in, shape_w2l / shape_l2w below, rely on it, and a shared node would
+  // make the flattened programs grow as 2^depth.)
+  {
+    std::vector<uint8_t> shape_refs(d->n_shapes, 0), node_refs(d->n_csg_nodes, 0);
+    auto take = [&](rt_ref r) { uint8_t &c = r >= 0 ? shape_refs[static_cast<size_t>(r)] : node_refs[static_cast<size_t>(~r)]; return ++c <= 1; };
+    bool tree = true;
+    for (uint32_t node = 0; node < d->n_csg_nodes && tree; ++node)
+      tree = take(d->csg_left[node]) && take(d->csg_right[node]);
+    for (uint32_t i = 0; i < d->n_objects && tree; ++i)
+      tree = take(d->objects[i]);
+    if (!tree)
+      return fail(RT_ERR_INVALID_ARGUMENT, "a shape or CSG node is referenced more than once (by objects[] and / or CSG children): every "
+                                           "object has exactly one owner, as in the reference's World; duplicate the shape instead");
+  }
+  // Limits of the fixed-capacity evaluator, checked bottom-up (children precede parents) before anything recursive runs.
+  {
+    std::vector<int32_t> depth(d->n_csg_nodes, 0), n_leaves(d->n_csg_nodes, 0);
+    for (uint32_t node = 0; node < d->n_csg_nodes; ++node) {
+      int32_t dep = 0, lv = 0;
+      for (rt_ref r : {d->csg_left[node], d->csg_right[node]}) {
+        dep = std::max(dep, r >= 0 ? 0 : depth[static_cast<size_t>(~r)]);
+        lv += r >= 0 ? 1 : n_leaves[static_cast<size_t>(~r)];
+      }
+      depth[node] = dep + 1;
+      n_leaves[node] = std::min(lv, RT_MAX_CSG_LEAVES + 1);
+      if (depth[node] > RT_MAX_CSG_DEPTH)
+        return fail(RT_ERR_INVALID_ARGUMENT, "CSG nesting deeper than RT_MAX_CSG_DEPTH");
+      if (n_leaves[node] > RT_MAX_CSG_LEAVES)
+        return fail(RT_ERR_INVALID_ARGUMENT, "CSG object has more than RT_MAX_CSG_LEAVES leaves");
+    }
+  }
   for (uint32_t node = 0; node < d->n_csg_nodes; ++node) {
     for (int side = 0; side < 2; ++side) {
       std::vector<int32_t> chain;
@@ -433,8 +469,6 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   }
   for (uint32_t i = 0; i < d->n_objects; ++i) {
     const rt_ref ref = d->objects[i];
-    if (!cb.ref_ok(ref, static_cast<int32_t>(d->n_csg_nodes)))
-      return fail(RT_ERR_INVALID_ARGUMENT, "objects[] reference out of range");
     if (ref >= 0) {
       rtd::ScanRec r{};
       std::memcpy(r.inv, d->shape_inv + 12 * static_cast<size_t>(ref), sizeof r.inv);
@@ -995,9 +1029,9 @@ rt_status rt_aa_jitter(int device, const uint64_t *sample_index, size_t n, float
   return RT_OK;
 }
 
-rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const float *in_dir, const float *normal, size_t n,
-                          float *dir_out) {
-  if (brdf_kind > RT_BRDF_SPECULAR || (n && (!pcg || !in_dir || !normal || !dir_out)))
+rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint32_t flags, uint64_t *pcg, const float *in_dir, const float *normal,
+                          size_t n, float *dir_out) {
+  if (brdf_kind > RT_BRDF_SPECULAR || (flags & ~RT_FLAG_EXACT_ARITHMETIC) || (n && (!pcg || !in_dir || !normal || !dir_out)))
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_scatter_rays: bad argument");
   if (n == 0)
     return RT_OK;
@@ -1010,8 +1044,11 @@ rt_status rt_scatter_rays(int device, uint32_t brdf_kind, uint64_t *pcg, const f
   if (e == hipSuccess) e = hipMemcpy(d_f, in_dir, 3 * n * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_f + 3 * n, normal, 3 * n * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(rtd::k_scatter_rays, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, brdf_kind, d_pcg,
-                       d_f, d_f + 3 * n, n, d_f + 6 * n);
+    const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+    if (flags & RT_FLAG_EXACT_ARITHMETIC)
+      hipLaunchKernelGGL(rtd::k_scatter_rays<false>, grid, dim3(256), 0, nullptr, brdf_kind, d_pcg, d_f, d_f + 3 * n, n, d_f + 6 * n);
+    else
+      hipLaunchKernelGGL(rtd::k_scatter_rays<true>, grid, dim3(256), 0, nullptr, brdf_kind, d_pcg, d_f, d_f + 3 * n, n, d_f + 6 * n);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(dir_out, d_f + 6 * n, 3 * n * sizeof(float), hipMemcpyDeviceToHost);

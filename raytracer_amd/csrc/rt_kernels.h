@@ -217,6 +217,8 @@ __global__ void k_aa_jitter(const uint64_t *k, size_t n, float *u, float *v) {
   aa_jitter(k[i], u[i], v[i]);
 }
 
+// FAST = the forms the default (FMA) path kernels use: rsq normalisation, cos/sin theta from square roots, v_sin / v_cos
+template <bool FAST>
 __global__ void k_scatter_rays(uint32_t brdf_kind, uint64_t *pcg, const float *in_dir, const float *normal, size_t n,
                                float *dir_out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,12 +226,12 @@ __global__ void k_scatter_rays(uint32_t brdf_kind, uint64_t *pcg, const float *i
     return;
   V3 d;
   if (brdf_kind == RT_BRDF_SPECULAR) {
-    d = specular_scatter_dir(ld3(in_dir + 3 * i), ld3(normal + 3 * i));
+    d = FAST ? specular_scatter_dir_fast(ld3(in_dir + 3 * i), ld3(normal + 3 * i)) : specular_scatter_dir(ld3(in_dir + 3 * i), ld3(normal + 3 * i));
   } else {
     Pcg p;
     p.state = pcg[2 * i];
     p.inc = pcg[2 * i + 1];
-    d = diffuse_scatter_dir<false>(normalized3(ld3(normal + 3 * i)), p);
+    d = diffuse_scatter_dir<FAST>(FAST ? normalized3_fast(ld3(normal + 3 * i)) : normalized3(ld3(normal + 3 * i)), p);
     pcg[2 * i] = p.state;
   }
   dir_out[3 * i + 0] = d.x;

@@ -41,9 +41,9 @@ template <int K> struct WideSlots<true, K> {
     if (valid) {
       const float4 v = reinterpret_cast<const float4 *>(s.wide_iso)[sphere];
       cx[k] = v.x, cy[k] = v.y, cz[k] = v.z, r2[k] = v.w;
-    } else { // empty slot: c = |oc|^2 + 1 makes disc <= -a < 0 (Cauchy-Schwarz), never a hit
+    } else { // empty slot: r^2 = -inf makes c = +inf and disc = -inf (NaN for a zero direction): never > 0, whatever the ray
       cx[k] = cy[k] = cz[k] = 0.f;
-      r2[k] = -1.f;
+      r2[k] = -INF_F;
     }
   }
   RT_DEV float disc(int k, const WideRay &r, float &b) const {
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       best.object = 0x7fffffff;
       best.shape = -1;
       scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best); // in object order: strict `<` among them
-      if (key != ~0ull) { // positions in the register rows ascend with the object index: the key's tie-break is the reference's
+      if (key != ~0ull && (unsigned)(key & 0xffffffffull) < (unsigned)s.n_wide) { // positions in the register rows ascend with the object index: the key's tie-break is the reference's
         const int2 ids = *reinterpret_cast<const int2 *>(&s.wide_recs[(int)(unsigned)(key & 0xffffffffull)].object); // {object, shape}
         const float t = __uint_as_float((unsigned)(key >> 32));
         if (t < best.t || (t == best.t && ids.x < best.object)) {

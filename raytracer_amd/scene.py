@@ -285,6 +285,10 @@ class SceneBuilder:
                "difference": abi.RT_CSG_DIFFERENCE, "fusion": abi.RT_CSG_FUSION}
         t = t or Transformation()
         a = self._a
+        # a norender object is MOVED into the CSG node that names it (scenefiles.hpp:1055-1065): one owner per object
+        for child in (left, right):
+            if child in a["objects"] or child in a["csg_left"] or child in a["csg_right"] or left == right:
+                raise ValueError("csg(): a child must be a norender object that no other CSG node uses (one owner per object)")
         node = len(a["csg_op"])
         a["csg_op"].append(ops[op])
         a["csg_left"].append(left)

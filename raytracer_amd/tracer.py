@@ -114,13 +114,14 @@ def aa_jitter(sample_index, device: int = 0):
     return u, v
 
 
-def scatter_rays(brdf_kind: int, pcg_state_inc, in_dir, normal, device: int = 0):
-    """BRDF::scatter_ray directions for a batch; returns (directions [n,3], advanced pcg [n,2])."""
+def scatter_rays(brdf_kind: int, pcg_state_inc, in_dir, normal, device: int = 0, exact: bool = True):
+    """BRDF::scatter_ray directions for a batch; returns (directions [n,3], advanced pcg [n,2]).
+    exact=True: the reference's formulas; False: the forms the default (FMA) path kernels use."""
     pcg = np.ascontiguousarray(pcg_state_inc, dtype=np.uint64).reshape(-1, 2).copy()
     in_dir = np.ascontiguousarray(in_dir, dtype=np.float32).reshape(-1, 3)
     normal = np.ascontiguousarray(normal, dtype=np.float32).reshape(-1, 3)
     out = np.zeros_like(normal)
-    check(dll().rt_scatter_rays(device, brdf_kind, pcg.ctypes.data, in_dir.ctypes.data, normal.ctypes.data, len(normal),
+    check(dll().rt_scatter_rays(device, brdf_kind, abi.RT_FLAG_EXACT_ARITHMETIC if exact else 0, pcg.ctypes.data, in_dir.ctypes.data, normal.ctypes.data, len(normal),
                                 out.ctypes.data))
     return out, pcg
 

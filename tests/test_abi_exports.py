@@ -67,3 +67,78 @@ def test_struct_layouts_match_the_c_header(tmp_path):
             assert getattr(getattr(abi, st), f).offset == int(val), name
         else:
             assert C.sizeof(getattr(abi, name)) == int(val), name
+
+
+def _create_status(scene):
+    import ctypes as C
+    handle = C.c_void_p()
+    desc = scene.desc()
+    st = dll().rt_scene_create(C.byref(desc), 0, C.byref(handle))
+    return st, dll().rt_last_error().decode()
+
+
+def test_scene_must_be_a_forest_and_within_csg_limits_checked_before_any_device_call():
+    """rt_scene_create validates on the host first, so these refusals need no GPU.  A World is a forest (every Object has
+    one owner: reference include/shapes.hpp:384-385,525): shared shapes / nodes are refused — the per-shape tables with the
+    CSG ancestors folded in rely on it — and so is a 40-level DAG (node i = ~(i-1) op ~(i-1)), which would otherwise be
+    flattened into 2^40 program entries, and a chain deeper than the evaluator's limit, without recursing into either."""
+    import numpy as np
+    from raytracer_amd.scene import SceneBuilder, Transformation
+
+    def base():
+        b = SceneBuilder()
+        m = b.material("diffuse", b.pigment_uniform((1, 1, 1)))
+        return b, m
+
+    # a leaf shared by two CSG objects (bypassing SceneBuilder's own check, as a C caller could)
+    b, m = base()
+    s0, s1, s2 = (b.sphere(Transformation(), m, norender=True) for _ in range(3))
+    b.csg(s0, s1, "union")
+    b.csg(s2, b.sphere(Transformation(), m, norender=True), "difference")
+    scene = b.build()
+    scene.csg_right = np.ascontiguousarray(np.array([s1, s1], dtype=np.int32))
+    st, msg = _create_status(scene)
+    assert st == abi.RT_ERR_INVALID_ARGUMENT and "more than once" in msg
+    # a shape that is both a top-level object and a CSG leaf
+    b, m = base()
+    top = b.sphere(Transformation(), m)
+    b.csg(b.sphere(Transformation(), m, norender=True), b.sphere(Transformation(), m, norender=True), "union")
+    scene = b.build()
+    scene.csg_left = np.ascontiguousarray(np.array([top], dtype=np.int32))
+    st, msg = _create_status(scene)
+    assert st == abi.RT_ERR_INVALID_ARGUMENT and "more than once" in msg
+    # DAG: node i uses node i-1 on both sides
+    b, m = base()
+    b.csg(b.sphere(Transformation(), m, norender=True), b.sphere(Transformation(), m, norender=True), "union", norender=True)
+    scene = b.build()
+    n = 40
+    scene.csg_op = np.zeros(n, dtype=np.uint8)
+    scene.csg_left = np.ascontiguousarray(np.array([0] + [~(i - 1) for i in range(1, n)], dtype=np.int32))
+    scene.csg_right = np.ascontiguousarray(np.array([1] + [~(i - 1) for i in range(1, n)], dtype=np.int32))
+    scene.csg_fwd = np.ascontiguousarray(np.tile(Transformation().fwd, n))
+    scene.csg_inv = np.ascontiguousarray(np.tile(Transformation().inv, n))
+    scene.objects = np.ascontiguousarray(np.array([~(n - 1)], dtype=np.int32))
+    st, msg = _create_status(scene)
+    assert st == abi.RT_ERR_INVALID_ARGUMENT and "more than once" in msg
+    # a chain of 50 000 nodes (a tree, but far deeper than RT_MAX_CSG_DEPTH): refused without recursion
+    n = 50_000
+    b, m = base()
+    scene = b.build()
+    scene.shape_kind = np.zeros(n + 1, dtype=np.uint8)
+    scene.shape_material = np.zeros(n + 1, dtype=np.uint32)
+    scene.shape_fwd = np.ascontiguousarray(np.tile(Transformation().fwd, n + 1))
+    scene.shape_inv = np.ascontiguousarray(np.tile(Transformation().inv, n + 1))
+    scene.csg_op = np.zeros(n, dtype=np.uint8)
+    scene.csg_left = np.ascontiguousarray(np.array([0] + [~(i - 1) for i in range(1, n)], dtype=np.int32))
+    scene.csg_right = np.ascontiguousarray(np.arange(1, n + 1, dtype=np.int32))
+    scene.csg_fwd = np.ascontiguousarray(np.tile(Transformation().fwd, n))
+    scene.csg_inv = np.ascontiguousarray(np.tile(Transformation().inv, n))
+    scene.objects = np.ascontiguousarray(np.array([~(n - 1)], dtype=np.int32))
+    st, msg = _create_status(scene)
+    assert st == abi.RT_ERR_INVALID_ARGUMENT and "RT_MAX_CSG_DEPTH" in msg
+    # SceneBuilder refuses the same things early
+    b, m = base()
+    s = b.sphere(Transformation(), m, norender=True)
+    b.csg(s, b.sphere(Transformation(), m, norender=True), "union")
+    with pytest.raises(ValueError):
+        b.csg(s, b.sphere(Transformation(), m, norender=True), "union")

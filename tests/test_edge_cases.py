@@ -156,6 +156,15 @@ def _same_with_and_without_bvh(gpu, scene, w=40, h=26, aa=2, **kw):
     rays_bvh = int(t.last_stats.rays)
     world.close()
     assert np.array_equal(linear, bvh) and rays == rays_bvh
+    # ... and against the CPU oracle on the same per-ray streams, at the bar the exact linear kernel meets
+    # (test_gpu_parity.test_path_same_streams_vs_oracle): only libm-ulp divergences remain
+    import oracle_lib as O
+    from raytracer_amd import abi
+    want, ostats = O.render(scene, O.make_cfg(w, h, "path", spp_edge=aa, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))
+    diff = np.abs(bvh - want).max(axis=-1)
+    assert (diff > 1e-4).mean() <= 0.03, f"{int((diff > 1e-4).sum())} of {diff.size} pixels differ from the oracle"
+    assert abs(float(bvh.mean()) - float(want.mean())) <= 0.01 * float(want.mean())
+    assert abs(rays_bvh - int(ostats.rays)) <= 0.08 * ostats.rays
 
 
 @pytest.mark.parametrize("scene_kw", [dict(csg_only=True), dict(n_spheres=0), dict(n_spheres=1)])
