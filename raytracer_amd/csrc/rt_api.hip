@@ -15,6 +15,7 @@
 
 #include "../../include/raytracer_amd.h"
 #include "rt_kernels.h"
+#include "rt_wavepath.h"
 #include "rt_bvh.h"
 #include "rt_tonemap.h"
 
@@ -486,6 +487,55 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       cb.tops.back().leaf_end = static_cast<int32_t>(cb.leaves.size());
     }
   }
+  // truth tables of the validity rule for small trees (rt_types.h CsgTop::tt)
+  std::vector<unsigned long long> leaf_tt(cb.leaves.size(), 0ull);
+  for (rtd::CsgTop &top : cb.tops) {
+    const int n_leaves = top.leaf_end - top.leaf_begin;
+    if (n_leaves > rtd::CSG_TT_MAX_LEAVES)
+      continue;
+    auto position = [&](int32_t shape) { // place of a shape among the tree's leaves (a forest: exactly one)
+      for (int j = 0; j < n_leaves; ++j)
+        if (cb.leaves[static_cast<size_t>(top.leaf_begin + j)].shape == shape)
+          return j;
+      return 0;
+    };
+    auto inside = [&](int begin, int end, uint32_t mask) { // CSGObject::is_point_inside of a subtree (shapes.hpp:438-457) on a mask
+      uint32_t bits = 0;
+      for (int e = begin; e < end; ++e) {
+        const rtd::CsgProgEntry &pe = cb.prog[static_cast<size_t>(e)];
+        if (!pe.is_op) {
+          bits = (bits << 1) | ((mask >> position(pe.arg)) & 1u);
+        } else {
+          const bool in2 = bits & 1u, in1 = (bits >> 1) & 1u;
+          const bool r = pe.arg == RT_CSG_INTERSECTION ? (in1 && in2) : pe.arg == RT_CSG_DIFFERENCE ? (in1 && !in2) : (in1 || in2);
+          bits = ((bits >> 2) << 1) | (r ? 1u : 0u);
+        }
+      }
+      return (bits & 1u) != 0;
+    };
+    for (int j = 0; j < n_leaves; ++j) {
+      const rtd::CsgLeaf &leaf = cb.leaves[static_cast<size_t>(top.leaf_begin + j)];
+      unsigned long long table = 0;
+      for (uint32_t mask = 0; mask < (1u << n_leaves); ++mask) {
+        bool valid = true;
+        for (int k = leaf.path_len - 1; k >= 0 && valid; --k) { // CSGObject::hit_on_obj{1,2}_valid (shapes.hpp:460-490), parent ... root
+          const rtd::CsgStep st = cb.path[static_cast<size_t>(leaf.path_begin + k)];
+          const int32_t *range = &cb.prog_range[4 * static_cast<size_t>(st.node) + 2 * static_cast<size_t>(1 - st.side)];
+          const bool in = inside(range[0], range[1], mask);
+          switch (d->csg_op[st.node]) {
+          case RT_CSG_UNION: break;
+          case RT_CSG_INTERSECTION: valid = in; break;
+          case RT_CSG_DIFFERENCE: valid = st.side == 0 ? !in : in; break;
+          default: valid = !in; break; // FUSION
+          }
+        }
+        if (valid)
+          table |= 1ull << mask;
+      }
+      leaf_tt[static_cast<size_t>(top.leaf_begin + j)] = table;
+    }
+    top.tt = 1;
+  }
   // world <-> local transforms of every shape with its CSG ancestors folded in (computed in binary64, rounded once)
   std::vector<float> shape_w2l(d->shape_inv, d->shape_inv + 12 * static_cast<size_t>(d->n_shapes));
   std::vector<float> shape_l2w(d->shape_fwd, d->shape_fwd + 12 * static_cast<size_t>(d->n_shapes));
@@ -647,6 +697,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, d->shape_material, d->n_shapes, &S.shape_material));
   UP(upload(sc, shade, &S.shape_shade));
   UP(upload(sc, cb.leaves, &S.csg_leaf));
+  UP(upload(sc, leaf_tt, &S.csg_leaf_tt));
   UP(upload(sc, cb.path, &S.csg_path));
   UP(upload(sc, d->csg_fwd, 12 * static_cast<size_t>(d->n_csg_nodes), &S.csg_fwd));
   UP(upload(sc, d->csg_inv, 12 * static_cast<size_t>(d->n_csg_nodes), &S.csg_inv));
@@ -780,12 +831,26 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     using L = rtd::PathLdsLimits;
     const bool small_tables = tab[0] <= L::SHAPES && tab[1] <= L::MATERIALS && tab[2] <= L::PIGMENTS && tab[3] <= L::CSG_LEAVES &&
                               tab[4] <= L::CSG_PATH && tab[5] <= L::CSG_NODES && tab[6] <= L::CSG_PROG && sc->dev.n_csg_tops <= L::CSG_TOPS;
-    path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>)
-                        : (small_tables ? reinterpret_cast<const void *>(rtd::k_render_path<true, true>)
-                                        : reinterpret_cast<const void *>(rtd::k_render_path<true>));
-    std::snprintf(kernel_name, sizeof kernel_name, "k_render_path<%s>", exact ? "EXACT" : (small_tables ? "FMA,TABLES_LDS" : "FMA"));
-    block = rtd::PATH_THREADS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
+    const bool use_wide = !exact && !use_bvh && sc->dev.n_wide >= 64; // measured: from 64 spheres in the register rows on, the wide kernel beats the per-lane scan
+    // Small worlds with small lookup tables (every sample scene of the reference): the pool run wave by wave (rt_wavepath.h)
+    const bool use_wave = small_tables && !use_bvh && !use_wide;
+    int nodes_per_level = 0, stacks_per_block = 1, node_words = rtd::NODE_WORDS; // nodes_per_level 0: the block size, set below
+    if (use_wave) {
+      static const int occ = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 5; }(); // tuning aid
+      path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path_wave<false, 4>)
+                          : (occ == 4   ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 4>)
+                             : occ == 6 ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 6>)
+                                        : reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 5>));
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s>", exact ? "EXACT" : "FMA");
+      block = rtd::WAVEPATH_THREADS;
+      dyn_lds = rtd::wave_lds_layout(tab[0], tab[1], tab[2], tab[3], tab[4], tab[5], tab[6], sc->dev.n_csg_tops).total;
+      nodes_per_level = 64, stacks_per_block = rtd::WAVEPATH_WAVES, node_words = rtd::WAVE_NODE_WORDS;
+    } else {
+      path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path<%s>", exact ? "EXACT" : "FMA");
+      block = rtd::PATH_THREADS;
+    }
     if (use_bvh) {
       // The tree (or its top) and, if they fit too, the leaf spheres go to LDS next to the workgroup's pool state:
       // 256 lanes when all of it fits 40 KiB (4 workgroups per CU), else 512 lanes within 72 KiB (2 per CU) — 4 waves
@@ -817,7 +882,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     }
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
-    if (!exact && !use_bvh && sc->dev.n_wide >= 64) { // measured: from 64 spheres in the register rows on, the wide kernel beats the per-lane scan
+    if (use_wide) {
       const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.
@@ -836,8 +901,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const uint64_t want = (p.n_samples + block - 1) / block;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
     // node stack of each workgroup: at most `block` nodes per depth level (rt_path.h)
-    p.pool_cap = static_cast<int32_t>(block) * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
-    const size_t stack_bytes = rtd::NODE_WORDS * static_cast<size_t>(p.pool_cap) * sizeof(float); // per workgroup
+    if (nodes_per_level == 0)
+      nodes_per_level = static_cast<int>(block);
+    p.pool_cap = nodes_per_level * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
+    const size_t stack_bytes = static_cast<size_t>(stacks_per_block) * node_words * static_cast<size_t>(p.pool_cap) * sizeof(float); // per workgroup
     if (ws.fixed) {
       // Fewer workgroups than the device could hold is fine for the result (sample values do not depend on which
       // workgroup traces them), but below one per CU the call would crawl: refuse instead.

@@ -483,6 +483,97 @@ RT_DEV bool csg_ray_intersection_fast(const Scene &s, const CsgTop &top, const R
   return found;
 }
 
+// The FMA evaluator for trees of at most LMAX <= 6 leaves (CsgTop::tt): no program is interpreted and no point is
+// transformed per candidate.  Every leaf is intersected once in its own frame (one composed transform); that also gives
+// the stretch of the ray that lies INSIDE the leaf — between the two roots of a sphere, on one side of a plane's root —
+// so "is this candidate inside leaf i" is two comparisons of ray parameters, the inside mask of a candidate is L such
+// pairs, and its validity is one bit of the leaf's truth table.  Same candidates, same order and tie rules as
+// csg_ray_intersection_fast; a point within rounding of another leaf's boundary may fall on the other side of it than
+// with the transformed-point test (statistical bar of the FMA kernels).  Everything is unrolled: the per-leaf values
+// stay in registers.
+template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const CsgTop &top, const Ray &ray_world, Hit &best) {
+  const int n_leaves = top.leaf_end - top.leaf_begin;
+  float t_in[LMAX], t_out[LMAX], c0[LMAX], c1[LMAX]; // inside stretch (open); candidate hits (INF: none)
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    t_in[j] = INF_F, t_out[j] = -INF_F, c0[j] = INF_F, c1[j] = INF_F;
+    if (j < n_leaves) {
+      const int shape = s.csg_leaf[top.leaf_begin + j].shape;
+      const float *inv = s.shape_w2l + 12 * shape;
+      if (s.shape_kind[shape] == RT_SHAPE_SPHERE) {
+        const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+        const float a = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
+        const float b = fmaf(o.x, d.x, fmaf(o.y, d.y, o.z * d.z));
+        const float c = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, -1.f)));
+        const float disc = fmaf(b, b, -(a * c));
+        if (disc > 0.f) {
+          const float sq = __builtin_amdgcn_sqrtf(disc), inv_a = __builtin_amdgcn_rcpf(a);
+          const float t1 = (-b - sq) * inv_a, t2 = (-b + sq) * inv_a; // a > 0: t1 < t2
+          t_in[j] = t1, t_out[j] = t2;
+          if (t1 > ray_world.tmin && t1 < ray_world.tmax) // Sphere::all_ray_intersections keeps the roots in the open range (shapes.hpp:236)
+            c0[j] = t1;
+          if (t2 > ray_world.tmin && t2 < ray_world.tmax)
+            c1[j] = t2;
+        }
+      } else { // plane: inside where o.z + t d.z < 0 (shapes.hpp:353-358)
+        const float oz = fmaf(inv[6], ray_world.o.x, fmaf(inv[7], ray_world.o.y, fmaf(inv[8], ray_world.o.z, inv[11])));
+        const float dz = fmaf(inv[6], ray_world.d.x, fmaf(inv[7], ray_world.d.y, inv[8] * ray_world.d.z));
+        const float t = -oz * __builtin_amdgcn_rcpf(dz);
+        if (!are_close(dz, 0.f) && !(t < ray_world.tmin || t > ray_world.tmax)) // Plane::ray_intersection (shapes.hpp:329-338)
+          c0[j] = t;
+        if (dz > 0.f)
+          t_in[j] = -INF_F, t_out[j] = t;
+        else if (dz < 0.f)
+          t_in[j] = t, t_out[j] = INF_F;
+        else if (oz < 0.f)
+          t_in[j] = -INF_F, t_out[j] = INF_F;
+      }
+    }
+  }
+  bool found = false;
+  float best_t = 0.f;
+  int best_leaf = -1;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < n_leaves) {
+      const unsigned long long table = s.csg_leaf_tt[top.leaf_begin + j];
+      bool first_of_leaf = true;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float t = r == 0 ? c0[j] : c1[j];
+        const bool better = t < INF_F && (!found || (first_of_leaf ? (t <= best_t) : (t < best_t))); // ties between leaves go to the later leaf
+        if (better) {
+          uint32_t mask = 0;
+#pragma unroll
+          for (int i = 0; i < LMAX; ++i)
+            mask |= (t > t_in[i] && t < t_out[i]) ? (1u << i) : 0u;
+          if ((table >> mask) & 1ull) {
+            found = true;
+            best_t = t;
+            best_leaf = j;
+            first_of_leaf = false;
+          }
+        }
+      }
+    }
+  }
+  if (found) {
+    const int best_shape = s.csg_leaf[top.leaf_begin + best_leaf].shape;
+    const float *inv = s.shape_w2l + 12 * best_shape;
+    const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+    const V3 p = mk3(fmaf(best_t, d.x, o.x), fmaf(best_t, d.y, o.y), fmaf(best_t, d.z, o.z));
+    V3 n = (s.shape_kind[best_shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
+    n = scale3(n, copysignf(1.0f, -fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z))));
+    best.t = best_t;
+    best.shape = best_shape;
+    best.object = top.object;
+    best.local = p;
+    best.point = hom_point_fast(s.shape_l2w + 12 * best_shape, p);
+    best.normal = hom_transposed_fast(inv, n);
+  }
+  return found;
+}
+
 // ---------------------------------------------------------------------------------------------
 // World — include/shapes.hpp:520-604
 // ---------------------------------------------------------------------------------------------
@@ -539,9 +630,9 @@ template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &r
     const float b = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
     const float c = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
     const float disc = fmaf(b, b, -(a * c));
-    if (disc > 0.f) {
-      const float sq = sqrtf(disc);
-      const float inv_a = 1.f / a;
+    if (disc > 0.f) { // v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded library forms: ~20 instructions per sphere that is hit
+      const float sq = __builtin_amdgcn_sqrtf(disc);
+      const float inv_a = __builtin_amdgcn_rcpf(a);
       const float t1 = (-b - sq) * inv_a;
       const float t2 = (-b + sq) * inv_a;
       float t = t1;
@@ -623,7 +714,12 @@ template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray,
   for (int i = 0; i < s.n_csg_tops; ++i) {
     const CsgTop top = s.csg_tops[i];
     Hit c;
-    const bool csg_hit = FAST ? csg_ray_intersection_fast(s, top, ray, c) : csg_ray_intersection(s, top, ray, c);
+    bool csg_hit;
+    if (FAST)
+      csg_hit = top.tt ? (top.leaf_end - top.leaf_begin <= 4 ? csg_ray_intersection_tt<4>(s, top, ray, c) : csg_ray_intersection_tt<CSG_TT_MAX_LEAVES>(s, top, ray, c))
+                       : csg_ray_intersection_fast(s, top, ray, c);
+    else
+      csg_hit = csg_ray_intersection(s, top, ray, c);
     if (csg_hit && (c.t < best.t || (c.t == best.t && c.object < best.object))) {
       best.t = c.t;
       best.object = c.object;
@@ -729,13 +825,21 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
 // ---------------------------------------------------------------------------------------------
 
 // UniformPigment / CheckeredPigment / ImagePigment::operator() — materials.hpp:64, 85-94, 120-137
-RT_DEV V3 pigment_eval(const Scene &s, uint32_t pg, float u, float v) {
+// FAST (FMA path kernels): the checker cell from u * n instead of u / (1.f / n) — two IEEE divisions and a reciprocal
+// less; the two forms can disagree only within an ulp of a cell edge.
+template <bool FAST = false> RT_DEV V3 pigment_eval(const Scene &s, uint32_t pg, float u, float v) {
   const int kind = s.pigment_kind[pg];
   if (kind == RT_PIGMENT_CHECKERED) {
-    float subinterval = 1.f / (float)s.pigment_n_intervals[pg]; // materials.hpp:81
-    int col = (int)(u / subinterval);
-    int row = (int)(v / subinterval);
-    return ((col + row) % 2 == 0) ? ld3(s.pigment_color1 + 3 * pg) : ld3(s.pigment_color2 + 3 * pg);
+    int col, row;
+    if (FAST) {
+      const float n = (float)s.pigment_n_intervals[pg];
+      col = (int)(u * n), row = (int)(v * n);
+    } else {
+      float subinterval = 1.f / (float)s.pigment_n_intervals[pg]; // materials.hpp:81
+      col = (int)(u / subinterval);
+      row = (int)(v / subinterval);
+    }
+    return (((col + row) & 1) == 0) ? ld3(s.pigment_color1 + 3 * pg) : ld3(s.pigment_color2 + 3 * pg);
   }
   if (kind == RT_PIGMENT_IMAGE) {
     int w = s.pigment_tex_width[pg], h = s.pigment_tex_height[pg];
@@ -765,6 +869,14 @@ RT_DEV void onb_from_e3(V3 e3, V3 &e1, V3 &e2) {
   e2 = mk3(b, sign + e3.y * e3.y * a, -e3.y);
 }
 
+RT_DEV void onb_from_e3_fast(V3 e3, V3 &e1, V3 &e2) { // the same basis with v_rcp_f32 and fused products
+  const float sign = copysignf(1.f, e3.z);
+  const float a = -__builtin_amdgcn_rcpf(sign + e3.z);
+  const float b = e3.x * e3.y * a;
+  e1 = mk3(fmaf(sign * e3.x, e3.x * a, 1.f), sign * b, -sign * e3.x);
+  e2 = mk3(b, fmaf(e3.y, e3.y * a, sign), -e3.y);
+}
+
 // DiffusiveBRDF::scatter_ray direction given the normalised normal — materials.hpp:199-211,
 // PCG::random_phong(1) — random.hpp:75-84
 // FAST: the same direction without the round trip through the angles — cos(acos(sqrt x)) = sqrt x,
@@ -772,15 +884,20 @@ RT_DEV void onb_from_e3(V3 e3, V3 &e1, V3 &e2) {
 // in revolutions.
 template <bool FAST> RT_DEV V3 diffuse_scatter_dir(V3 e3, Pcg &pcg) {
   V3 e1, e2;
-  onb_from_e3(e3, e1, e2);
+  if (FAST)
+    onb_from_e3_fast(e3, e1, e2);
+  else
+    onb_from_e3(e3, e1, e2);
   float x = pcg_random_float(pcg);
   float y = pcg_random_float(pcg);
   float st, ct, sp, cp;
   if (FAST) {
-    ct = sqrtf(x);
-    st = sqrtf(fmaxf(1.f - x, 0.f));
+    ct = __builtin_amdgcn_sqrtf(x);
+    st = __builtin_amdgcn_sqrtf(fmaxf(1.f - x, 0.f));
     sp = __builtin_amdgcn_sinf(y);
     cp = __builtin_amdgcn_cosf(y);
+    const float sc = st * cp, ss = st * sp;
+    return mk3(fmaf(e1.x, sc, fmaf(e2.x, ss, e3.x * ct)), fmaf(e1.y, sc, fmaf(e2.y, ss, e3.y * ct)), fmaf(e1.z, sc, fmaf(e2.z, ss, e3.z * ct)));
   } else {
     // pow(x, 1.f/(n+1)) with n = 1 is x^(1/2): sqrtf is correctly rounded, which is what glibc's powf
     // returns for this exponent (the device powf is not), so theta tracks the reference more closely.

@@ -312,16 +312,16 @@ template <int T, bool FAST> struct PathBlock {
           float u, v;
           hit_uv(s, h, m, u, v);
           if (!(mflags & 2u))
-            reflected = pigment_eval(s, s.material_brdf_pigment[m], u, v);
+            reflected = pigment_eval<FAST>(s, s.material_brdf_pigment[m], u, v);
           if (!(mflags & 4u))
-            emitted = pigment_eval(s, s.material_emission_pigment[m], u, v);
+            emitted = pigment_eval<FAST>(s, s.material_emission_pigment[m], u, v);
         }
         const float hit_lum = fmaxf(fmaxf(reflected.x, reflected.y), reflected.z);
         push = hit_lum > 0.f;
         if (depth > p.roulette) {
           const float q = fmaxf(1.f - hit_lum, 0.05f);
           if (pcg_random_float(pcg) > q)
-            reflected = scale3(reflected, 1.f / (1.f - q));
+            reflected = scale3(reflected, FAST ? __builtin_amdgcn_rcpf(1.f - q) : 1.f / (1.f - q));
           else
             push = false;
         }

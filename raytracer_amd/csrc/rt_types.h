@@ -24,8 +24,13 @@ struct CsgTop {        // one top-level CSGObject
   int32_t object;      // index in World::objects
   int32_t leaf_begin;  // range in csg_leaf[]
   int32_t leaf_end;
-  int32_t pad;
+  int32_t tt;          // 1: the tree has at most CSG_TT_MAX_LEAVES leaves and csg_leaf_tt[] holds their truth tables
 };
+// Truth-table form of the validity rule (FMA path kernels, trees of up to 6 leaves): a boundary hit on leaf l is kept iff
+// every ancestor's rule accepts it, and each rule looks only at "is the point inside the sibling subtree", a boolean
+// function of the leaves' inside tests — so validity is ONE boolean function of the inside mask (bit i: the point is
+// inside leaf i of the tree), tabulated by the host: bit m of csg_leaf_tt[l] = "kept when the inside mask is m".
+constexpr int CSG_TT_MAX_LEAVES = 6;
 
 struct CsgLeaf {       // one Sphere/Plane leaf below a top-level CSG object (left-to-right order)
   int32_t shape;
@@ -97,6 +102,7 @@ struct Scene {
   const float *shape_l2w;         // [n_shapes][12]
   // CSG tables
   const CsgLeaf *csg_leaf;
+  const unsigned long long *csg_leaf_tt; // [n leaves] truth tables (see CsgTop::tt)
   const CsgStep *csg_path;
   const float *csg_fwd;           // [n_nodes][12]
   const float *csg_inv;

