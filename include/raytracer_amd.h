@@ -269,6 +269,54 @@ RT_API rt_status rt_render_noalloc(rt_scene *scene, const rt_camera *camera, con
 RT_API rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg,
                          float *rgb_out_host, rt_stats *stats);
 
+/* The whole fire_all_rays call into host memory, with its progress callback: ImageTracer::fire_all_rays(func, callback)
+ * (include/cameras.hpp:221-251) reports (col + 1) / W after every column (cameras.hpp:249); here the frame is rendered
+ * as n_slices horizontal slices queued back to back on one stream, `progress` is called with rows_done / height in
+ * (0, 1] as each finishes, and ONE device-to-host copy delivers HdrImage::pixels at the end.  The framebuffer in HBM
+ * belongs to the scene handle and is reused from frame to frame (no allocation per frame once it is large enough).
+ * cfg must describe the whole image.  progress may be NULL (then the frame is one launch). */
+typedef void (*rt_progress_fn)(float fraction_done, void *user);
+RT_API rt_status rt_render_frame_host(rt_scene *scene, const rt_camera *camera, const rt_render_cfg *cfg, float *rgb_out_host,
+                                      int n_slices, rt_progress_fn progress, void *user, rt_stats *stats);
+
+/* One frame on several GPUs of one node ------------------------------------------------------------
+ * Replaces the same call, tracer.fire_all_rays(...) at src/raytracer.cpp:151-153, when more than one GPU is visible
+ * (the reference is single-threaded; its README only suggests GNU parallel over animation frames).  The image rows
+ * are dealt round-robin to the ranks (row r, r + n, r + 2n, ... to rank r: neighbouring rows cost alike), every rank
+ * renders its rows on its own device and stream from its own replica of the World, the bands are gathered on the first
+ * rank's device with RCCL point-to-point calls (ncclSend / ncclRecv in one group, every peer over its own xGMI link)
+ * and put in place there.  No exchange happens while rendering.  Because a sample's random streams depend only on its
+ * global index and sample values are integer sums, the frame is bit-identical to rt_render's for any number of ranks.
+ *
+ * devices: rank r renders on devices[r]; n_devices == 0 means every visible device.  A device may be listed several
+ * times ("virtual ranks" sharing one GPU, for tests and rehearsals); RCCL cannot hold one device twice in a
+ * communicator, so then — or with RT_MULTI_PEER_COPIES — the bands travel by hipMemcpyPeerAsync instead.
+ * RT_MULTI_RCCL_SELF: rank 0's own band goes through ncclSend / ncclRecv to itself as well (so that the RCCL path can
+ * be exercised on a single GPU). */
+#define RT_MULTI_PEER_COPIES 1u
+#define RT_MULTI_RCCL_SELF 2u
+#define RT_MULTI_MAX_TIMED_RANKS 16
+typedef struct rt_multi rt_multi; /* opaque */
+typedef struct rt_multi_timing {
+  int32_t n_ranks;
+  float slowest_render_ms;                      /* the frame's kernel time: max over ranks                               */
+  float gather_ms;                              /* from the last rank's render finishing to the assembled frame (host clock) */
+  float render_ms[RT_MULTI_MAX_TIMED_RANKS];    /* per rank, HIP events on its stream                                     */
+  uint64_t rays[RT_MULTI_MAX_TIMED_RANKS];      /* per rank                                                               */
+} rt_multi_timing;
+RT_API rt_status rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, uint32_t flags, rt_multi **out);
+RT_API void rt_multi_destroy(rt_multi *multi);
+RT_API int rt_multi_rank_count(const rt_multi *multi);
+RT_API int rt_multi_uses_rccl(const rt_multi *multi); /* 1: the gather goes through RCCL, 0: peer copies */
+/* cfg describes the whole image (band fields as for a whole-image rt_render).  rgb_out_device0: device pointer on
+ * devices[0], height * width * 3 floats.  Synchronises before returning.  stats (summed over ranks; kernel_ms = the
+ * slowest rank) and timing may be NULL. */
+RT_API rt_status rt_multi_render(rt_multi *multi, const rt_camera *camera, const rt_render_cfg *cfg, float *rgb_out_device0,
+                                 rt_stats *stats, rt_multi_timing *timing);
+/* The same into host memory (HdrImage::pixels): one device-to-host copy from the first rank's device. */
+RT_API rt_status rt_multi_render_host(rt_multi *multi, const rt_camera *camera, const rt_render_cfg *cfg, float *rgb_out_host,
+                                      rt_stats *stats, rt_multi_timing *timing);
+
 /* Batch closest-hit --------------------------------------------------------------------------------
  * Replaces: World::ray_intersection (include/shapes.hpp:547-561) for n rays at once; one ray per
  * lane.  rays / hits are HOST pointers (debug / parity entry point, not a hot path). */

@@ -98,6 +98,14 @@ class rt_tonemap_cfg(C.Structure):
                 ("delta", C.c_float), ("flags", C.c_uint32)]
 
 
+RT_MULTI_PEER_COPIES, RT_MULTI_RCCL_SELF, RT_MULTI_MAX_TIMED_RANKS = 1, 2, 16
+
+
+class rt_multi_timing(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("slowest_render_ms", C.c_float), ("gather_ms", C.c_float),
+                ("render_ms", C.c_float * RT_MULTI_MAX_TIMED_RANKS), ("rays", C.c_uint64 * RT_MULTI_MAX_TIMED_RANKS)]
+
+
 PROTOTYPES = {
     "rt_last_error": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
@@ -109,6 +117,16 @@ PROTOTYPES = {
                                     C.POINTER(rt_stats)]),
     "rt_render_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p,
                                  C.POINTER(rt_stats)]),
+    "rt_render_frame_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(rt_stats)]),
+    "rt_multi_create": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_rank_count": (C.c_int, [C.c_void_p]),
+    "rt_multi_uses_rccl": (C.c_int, [C.c_void_p]),
+    "rt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.POINTER(rt_stats),
+                                  C.POINTER(rt_multi_timing)]),
+    "rt_multi_render_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.POINTER(rt_stats),
+                                       C.POINTER(rt_multi_timing)]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_offset_if_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_aa_jitter": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -105,7 +107,9 @@ struct rt_scene {
   unsigned long long *counters = nullptr; // rtd::COUNTER_WORDS x u64
   int32_t tab[7] = {0, 0, 0, 0, 0, 0, 0}; // table sizes: shapes, materials, pigments, csg leaves / chain steps / nodes / program entries
   DeviceBuffer samples, stack;   // grow-only scratch reused across renders
+  DeviceBuffer frame;            // rt_render_frame_host: the frame while it is in HBM
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> slice_events; // rt_render_frame_host: one per progress report
 };
 
 namespace {
@@ -618,6 +622,17 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       }
     }
   }
+  std::vector<int32_t> shape_origin(4 * static_cast<size_t>(d->n_shapes), -1);
+  for (uint32_t i = 0; i < d->n_shapes; ++i)
+    shape_origin[4 * static_cast<size_t>(i) + 3] = 0;
+  for (const rtd::ScanRec &r : spheres)
+    shape_origin[4 * static_cast<size_t>(r.shape) + 0] = r.object, shape_origin[4 * static_cast<size_t>(r.shape) + 3] = 1;
+  for (const rtd::ScanRec &r : planes)
+    shape_origin[4 * static_cast<size_t>(r.shape) + 0] = r.object;
+  for (size_t k = 0; k < wide_recs.size(); ++k)
+    shape_origin[4 * static_cast<size_t>(wide_recs[k].shape) + 1] = static_cast<int32_t>(k);
+  for (size_t k = 0; k < bvh_recs.size(); ++k)
+    shape_origin[4 * static_cast<size_t>(bvh_recs[k].shape) + 2] = static_cast<int32_t>(k);
   std::vector<uint8_t> needs_uv(d->n_materials);
   for (uint32_t m = 0; m < d->n_materials; ++m)
     needs_uv[m] = d->pigment_kind[d->material_brdf_pigment[m]] != RT_PIGMENT_UNIFORM ||
@@ -696,6 +711,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, d->shape_kind, d->n_shapes, &S.shape_kind));
   UP(upload(sc, d->shape_material, d->n_shapes, &S.shape_material));
   UP(upload(sc, shade, &S.shape_shade));
+  UP(upload(sc, shape_origin, &S.shape_origin));
   UP(upload(sc, cb.leaves, &S.csg_leaf));
   UP(upload(sc, leaf_tt, &S.csg_leaf_tt));
   UP(upload(sc, cb.path, &S.csg_path));
@@ -741,6 +757,8 @@ void rt_scene_destroy(rt_scene *sc) {
   if (sc->counters) (void)hipFree(sc->counters);
   if (sc->samples.ptr) (void)hipFree(sc->samples.ptr);
   if (sc->stack.ptr) (void)hipFree(sc->stack.ptr);
+  if (sc->frame.ptr) (void)hipFree(sc->frame.ptr);
+  for (hipEvent_t e : sc->slice_events) (void)hipEventDestroy(e);
   if (sc->ev0) (void)hipEventDestroy(sc->ev0);
   if (sc->ev1) (void)hipEventDestroy(sc->ev1);
   delete sc;
@@ -756,6 +774,16 @@ namespace {
 struct Workspace {
   unsigned char *fixed = nullptr; // device address, 256-byte aligned; nullptr: allocate in the scene handle
   size_t fixed_bytes = 0;
+  // A frame rendered as several launches on one stream (rt_render_frame_host, rt_multi_render): the tallies keep
+  // accumulating across them (only the first launch zeroes them) and are read once, by read_tallies().
+  bool keep_tallies = false;
+  struct LaunchInfo *info = nullptr; // out: what was launched
+};
+struct LaunchInfo {
+  unsigned grid = 0, block = 0;
+  uint64_t n_samples = 0;
+  unsigned long long *counters = nullptr;
+  char kernel[48] = "";
 };
 constexpr size_t WS_COUNTER_BYTES = 1024; // >= rtd::COUNTER_WORDS * 8, keeps what follows 256-byte aligned
 static_assert(WS_COUNTER_BYTES >= rtd::COUNTER_WORDS * sizeof(unsigned long long), "counter area too small");
@@ -837,7 +865,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const bool use_wave = small_tables && !use_bvh && !use_wide;
     int nodes_per_level = 0, stacks_per_block = 1, node_words = rtd::NODE_WORDS; // nodes_per_level 0: the block size, set below
     if (use_wave) {
-      static const int occ = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 5; }(); // tuning aid
+      // waves per SIMD: 4 (128 VGPRs, no spills) is best without CSG objects, 5 (96 VGPRs) with them — measured on C3 / C4
+      static const int occ_env = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 0; }(); // tuning aid
+      const int occ = occ_env ? occ_env : (sc->dev.n_csg_tops > 0 ? 5 : 4);
       path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path_wave<false, 4>)
                           : (occ == 4   ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 4>)
                              : occ == 6 ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 6>)
@@ -927,7 +957,13 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * 8)); // 8 waves per SIMD, grid-stride
   }
 
-  RT_HIP(hipMemsetAsync(p.counters, 0, rtd::COUNTER_WORDS * sizeof(unsigned long long), stream));
+  (void)hipGetLastError(); // an error left behind by an earlier, unrelated call must not be reported as this launch's
+  // counter 0 is the call's sample queue; the rest are tallies
+  RT_HIP(hipMemsetAsync(p.counters, 0, (ws.keep_tallies ? 1 : rtd::COUNTER_WORDS) * sizeof(unsigned long long), stream));
+  if (ws.info) {
+    ws.info->grid = grid, ws.info->block = block, ws.info->n_samples = p.n_samples, ws.info->counters = p.counters;
+    std::memcpy(ws.info->kernel, kernel_name, sizeof ws.info->kernel);
+  }
   if (stats)
     RT_HIP(hipEventRecord(sc->ev0, stream));
   switch (cfg->mode) {
@@ -1019,6 +1055,388 @@ rt_status rt_render_host(rt_scene *sc, const rt_camera *cam, const rt_render_cfg
   }
   (void)hipFree(fb);
   return st;
+}
+
+} // extern "C"
+
+namespace {
+
+// Ray / capped-sample tallies of the launches since the last zeroing (the stream they ran on must be idle).
+rt_status read_tallies(const unsigned long long *counters, uint64_t *rays, uint64_t *capped) {
+  unsigned long long c[rtd::COUNTER_WORDS];
+  RT_HIP(hipMemcpy(c, counters, sizeof c, hipMemcpyDeviceToHost));
+  *rays = *capped = 0;
+  for (int k = 0; k < rtd::COUNTER_SLOTS; ++k)
+    *rays += c[rtd::COUNTER_BASE + 2 * k], *capped += c[rtd::COUNTER_BASE + 2 * k + 1];
+  return RT_OK;
+}
+
+bool whole_image(const rt_render_cfg *cfg) {
+  return cfg->band_rows == cfg->height && cfg->band_offset == 0 && cfg->n_local_rows == cfg->height;
+}
+
+} // namespace
+
+extern "C" {
+
+rt_status rt_render_frame_host(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, int n_slices,
+                               rt_progress_fn progress, void *user, rt_stats *stats) {
+  if (!sc || !cam || !cfg || !rgb_out_host)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_frame_host: NULL argument");
+  if (rt_status st = check_cfg(cfg))
+    return st;
+  if (!whole_image(cfg))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_frame_host renders whole images (band_rows = n_local_rows = height, band_offset = 0)");
+  RT_ON_DEVICE(sc->device);
+  const size_t row_floats = static_cast<size_t>(cfg->width) * 3, bytes = static_cast<size_t>(cfg->height) * row_floats * sizeof(float);
+  if (rt_status st = ensure(sc->frame, bytes))
+    return st;
+  float *fb = static_cast<float *>(sc->frame.ptr);
+  n_slices = progress ? std::clamp(n_slices, 1, std::min(cfg->height, 256)) : 1;
+  while (sc->slice_events.size() < static_cast<size_t>(n_slices) + 1) {
+    hipEvent_t e = nullptr;
+    RT_HIP(hipEventCreate(&e));
+    sc->slice_events.push_back(e);
+  }
+  hipStream_t stream = nullptr;
+  Workspace ws;
+  LaunchInfo info;
+  ws.info = &info;
+  RT_HIP(hipEventRecord(sc->slice_events[0], stream));
+  std::vector<int> row_end(static_cast<size_t>(n_slices));
+  for (int i = 0; i < n_slices; ++i) { // all slices are queued before the first report: the GPU never waits for the host
+    const int row0 = static_cast<int>(static_cast<long long>(cfg->height) * i / n_slices);
+    const int row1 = static_cast<int>(static_cast<long long>(cfg->height) * (i + 1) / n_slices);
+    row_end[static_cast<size_t>(i)] = row1;
+    rt_render_cfg slice = *cfg;
+    slice.band_rows = slice.n_local_rows = row1 - row0, slice.band_stride = cfg->height, slice.band_offset = row0;
+    ws.keep_tallies = i > 0;
+    if (rt_status st = render_impl(sc, cam, &slice, fb + static_cast<size_t>(row0) * row_floats, stream, nullptr, ws))
+      return st;
+    RT_HIP(hipEventRecord(sc->slice_events[static_cast<size_t>(i) + 1], stream));
+  }
+  for (int i = 0; i < n_slices && progress; ++i) {
+    RT_HIP(hipEventSynchronize(sc->slice_events[static_cast<size_t>(i) + 1]));
+    progress(static_cast<float>(row_end[static_cast<size_t>(i)]) / static_cast<float>(cfg->height), user);
+  }
+  RT_HIP(hipMemcpy(rgb_out_host, fb, bytes, hipMemcpyDeviceToHost)); // one copy; synchronises the stream
+  if (stats) {
+    uint64_t rays = 0, capped = 0;
+    if (rt_status st = read_tallies(info.counters, &rays, &capped))
+      return st;
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, sc->slice_events[0], sc->slice_events[static_cast<size_t>(n_slices)]));
+    std::memset(stats, 0, sizeof *stats);
+    stats->rays = rays, stats->capped_samples = capped, stats->kernel_ms = ms;
+    stats->samples = static_cast<uint64_t>(cfg->width) * cfg->height * cfg->spp_edge * cfg->spp_edge;
+    stats->grid = info.grid, stats->block = info.block;
+    std::memcpy(stats->kernel, info.kernel, sizeof stats->kernel);
+  }
+  return RT_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// One frame on several GPUs of one node: rows dealt round-robin, one scene replica, stream and band
+// buffer per device, gather to the first device with RCCL point-to-point calls (xGMI is point to point: every peer
+// sends over its own link, nothing is gained from a ring at <= 12 MB per peer).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// RCCL is loaded on first use (single-GPU callers never pay for it, and a process that already holds a copy — PyTorch
+// bundles one under the same soname — keeps using that copy).
+struct Rccl {
+  using Comm = void *;
+  int (*CommInitAll)(Comm *, int, const int *) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  static constexpr int Float32 = 7; // ncclFloat32 (rccl.h)
+  bool ok = false;
+  std::string error;
+};
+Rccl &rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+        break;
+    if (!h) {
+      x.error = std::string("librccl.so.1 not found: ") + dlerror();
+      return x;
+    }
+    auto sym = [&](const char *n) {
+      void *p = dlsym(h, n);
+      if (!p)
+        x.error = std::string("RCCL symbol missing: ") + n;
+      return p;
+    };
+    x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+    x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+    x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
+    x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+    x.ok = x.error.empty();
+    return x;
+  }();
+  return r;
+}
+#define RT_NCCL(call)                                                                                      \
+  do {                                                                                                     \
+    int e_ = (call);                                                                                       \
+    if (e_ != 0)                                                                                           \
+      return fail(RT_ERR_HIP, std::string(#call) + ": " + rccl().GetErrorString(e_));                     \
+  } while (0)
+
+// rows of one rank's compact band buffer -> their places in the row-major frame (image row = local row * n_ranks + rank)
+__global__ void __launch_bounds__(256) k_place_rows(const float4 *band, float4 *frame, int n_local_rows, int row_quads, int rank, int n_ranks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)n_local_rows * row_quads;
+  if (i >= n)
+    return;
+  const size_t lr = i / row_quads, q = i - lr * row_quads;
+  frame[(lr * n_ranks + rank) * row_quads + q] = band[i];
+}
+__global__ void __launch_bounds__(256) k_place_rows_scalar(const float *band, float *frame, int n_local_rows, int row_floats, int rank, int n_ranks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)n_local_rows * row_floats;
+  if (i >= n)
+    return;
+  const size_t lr = i / row_floats, q = i - lr * row_floats;
+  frame[(lr * n_ranks + rank) * row_floats + q] = band[i];
+}
+
+} // namespace
+
+struct rt_multi {
+  std::vector<int> devices;             // rank r renders on devices[r]; rank 0's device assembles the frame
+  std::vector<rt_scene *> scenes;       // one replica of the World per rank
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> begun, done;  // per rank: around its render
+  std::vector<DeviceBuffer> bands;      // per rank, on its device: its rows, compact
+  std::vector<DeviceBuffer> landing;    // per rank >= 1, on devices[0]: where its band arrives
+  DeviceBuffer frame;                   // on devices[0]: rt_multi_render_host's frame
+  std::vector<Rccl::Comm> comms;        // empty: peer copies instead of RCCL
+  bool self_send = false;               // RT_MULTI_RCCL_SELF: rank 0's own band travels through RCCL too
+};
+
+extern "C" {
+
+void rt_multi_destroy(rt_multi *m) {
+  if (!m)
+    return;
+  for (Rccl::Comm c : m->comms)
+    if (c)
+      (void)rccl().CommDestroy(c);
+  for (size_t r = 0; r < m->devices.size(); ++r) {
+    DeviceGuard guard(m->devices[r]);
+    if (r < m->streams.size() && m->streams[r]) (void)hipStreamDestroy(m->streams[r]);
+    if (r < m->begun.size() && m->begun[r]) (void)hipEventDestroy(m->begun[r]);
+    if (r < m->done.size() && m->done[r]) (void)hipEventDestroy(m->done[r]);
+    if (r < m->bands.size() && m->bands[r].ptr) (void)hipFree(m->bands[r].ptr);
+    if (r < m->scenes.size()) rt_scene_destroy(m->scenes[r]);
+  }
+  if (!m->devices.empty()) {
+    DeviceGuard guard(m->devices[0]);
+    for (DeviceBuffer &b : m->landing)
+      if (b.ptr) (void)hipFree(b.ptr);
+    if (m->frame.ptr) (void)hipFree(m->frame.ptr);
+  }
+  delete m;
+}
+
+rt_status rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, uint32_t flags, rt_multi **out) {
+  if (!desc || !out || n_devices < 0 || (n_devices > 0 && !devices))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_create: NULL argument");
+  *out = nullptr;
+  if (flags & ~(RT_MULTI_PEER_COPIES | RT_MULTI_RCCL_SELF))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_create: unknown flag");
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible == 0)
+    return fail(RT_ERR_NO_DEVICE, "rt_multi_create: no HIP device visible");
+  rt_multi *m = new (std::nothrow) rt_multi();
+  if (!m)
+    return fail(RT_ERR_OUT_OF_MEMORY, "rt_multi_create: host allocation failed");
+  auto bail = [&](rt_status st) {
+    rt_multi_destroy(m);
+    return st;
+  };
+  for (int r = 0; r < n_devices; ++r)
+    if (devices[r] < 0 || devices[r] >= visible)
+      return bail(fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_create: device index out of range"));
+  if (n_devices == 0)
+    for (int d = 0; d < visible; ++d)
+      m->devices.push_back(d); // every visible device
+  else
+    m->devices.assign(devices, devices + n_devices);
+  const size_t n = m->devices.size();
+  bool distinct = true;
+  for (size_t r = 0; r < n; ++r)
+    for (size_t q = 0; q < r; ++q)
+      distinct = distinct && m->devices[q] != m->devices[r];
+  m->scenes.assign(n, nullptr), m->streams.assign(n, nullptr), m->begun.assign(n, nullptr), m->done.assign(n, nullptr);
+  m->bands.assign(n, DeviceBuffer{}), m->landing.assign(n, DeviceBuffer{});
+  for (size_t r = 0; r < n; ++r) {
+    if (rt_status st = rt_scene_create(desc, m->devices[r], &m->scenes[r]))
+      return bail(st);
+    DeviceGuard guard(m->devices[r]);
+    if (guard.err != hipSuccess || hipStreamCreateWithFlags(&m->streams[r], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&m->begun[r]) != hipSuccess || hipEventCreate(&m->done[r]) != hipSuccess)
+      return bail(fail(RT_ERR_HIP, "rt_multi_create: stream / event creation failed"));
+  }
+  // Gather transport: RCCL when every rank has its own device (a communicator cannot hold one device twice); ranks that
+  // share a device (several "virtual ranks" on one GPU: tests, rehearsals) or RT_MULTI_PEER_COPIES use peer copies.
+  m->self_send = (flags & RT_MULTI_RCCL_SELF) != 0;
+  const bool want_rccl = distinct && !(flags & RT_MULTI_PEER_COPIES) && (n > 1 || m->self_send);
+  if (want_rccl) {
+    if (!rccl().ok)
+      return bail(fail(RT_ERR_HIP, "rt_multi_create: " + rccl().error));
+    m->comms.assign(n, nullptr);
+    int e = rccl().CommInitAll(m->comms.data(), static_cast<int>(n), m->devices.data());
+    if (e != 0)
+      return bail(fail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(e)));
+  }
+  *out = m;
+  return RT_OK;
+}
+
+int rt_multi_rank_count(const rt_multi *m) { return m ? static_cast<int>(m->devices.size()) : 0; }
+int rt_multi_uses_rccl(const rt_multi *m) { return m && !m->comms.empty() ? 1 : 0; }
+
+rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device0, rt_stats *stats,
+                          rt_multi_timing *timing) {
+  if (!m || !cam || !cfg || !rgb_out_device0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render: NULL argument");
+  if (rt_status st = check_cfg(cfg))
+    return st;
+  if (!whole_image(cfg))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render renders whole images (band_rows = n_local_rows = height, band_offset = 0): the rows are dealt to the devices inside");
+  const int n = static_cast<int>(m->devices.size());
+  const size_t row_floats = static_cast<size_t>(cfg->width) * 3;
+  std::vector<int> rows(static_cast<size_t>(n));
+  std::vector<LaunchInfo> info(static_cast<size_t>(n));
+  // 1. every rank renders its rows (row r, r + n, r + 2n, ...) into its compact band buffer; launches are asynchronous,
+  //    so one host thread keeps all devices busy
+  for (int r = 0; r < n; ++r) {
+    rows[r] = cfg->height > r ? (cfg->height - r + n - 1) / n : 0;
+    if (rows[r] == 0)
+      continue;
+    RT_ON_DEVICE(m->devices[r]);
+    if (rt_status st = ensure(m->bands[r], static_cast<size_t>(rows[r]) * row_floats * sizeof(float)))
+      return st;
+    rt_render_cfg band = *cfg;
+    band.band_rows = 1, band.band_stride = n, band.band_offset = r, band.n_local_rows = rows[r];
+    Workspace ws;
+    ws.info = &info[r];
+    RT_HIP(hipEventRecord(m->begun[r], m->streams[r]));
+    if (rt_status st = render_impl(m->scenes[r], cam, &band, static_cast<float *>(m->bands[r].ptr), m->streams[r], nullptr, ws))
+      return st;
+    RT_HIP(hipEventRecord(m->done[r], m->streams[r]));
+  }
+  // 2. gather to rank 0's device and put the rows in place
+  RT_ON_DEVICE(m->devices[0]);
+  hipStream_t s0 = m->streams[0];
+  const bool use_rccl = !m->comms.empty();
+  const int first_moved = use_rccl && m->self_send ? 0 : 1;
+  for (int r = first_moved; r < n; ++r)
+    if (rows[r])
+      if (rt_status st = ensure(m->landing[r], static_cast<size_t>(rows[r]) * row_floats * sizeof(float)))
+        return st;
+  if (use_rccl) {
+    RT_NCCL(rccl().GroupStart());
+    for (int r = first_moved; r < n; ++r) {
+      if (!rows[r])
+        continue;
+      const size_t count = static_cast<size_t>(rows[r]) * row_floats;
+      RT_NCCL(rccl().Send(m->bands[r].ptr, count, Rccl::Float32, 0, m->comms[r], m->streams[r])); // ordered after rank r's render
+      RT_NCCL(rccl().Recv(m->landing[r].ptr, count, Rccl::Float32, r, m->comms[0], s0));
+    }
+    RT_NCCL(rccl().GroupEnd());
+  } else {
+    for (int r = 1; r < n; ++r) {
+      if (!rows[r])
+        continue;
+      RT_HIP(hipStreamWaitEvent(s0, m->done[r], 0));
+      RT_HIP(hipMemcpyPeerAsync(m->landing[r].ptr, m->devices[0], m->bands[r].ptr, m->devices[r], static_cast<size_t>(rows[r]) * row_floats * sizeof(float), s0));
+    }
+  }
+  for (int r = 0; r < n; ++r) {
+    if (!rows[r])
+      continue;
+    const float *src = static_cast<const float *>(r >= first_moved ? m->landing[r].ptr : m->bands[r].ptr);
+    if (row_floats % 4 == 0 && reinterpret_cast<uintptr_t>(rgb_out_device0) % 16 == 0) {
+      const size_t quads = static_cast<size_t>(rows[r]) * (row_floats / 4);
+      hipLaunchKernelGGL(k_place_rows, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, s0, reinterpret_cast<const float4 *>(src),
+                         reinterpret_cast<float4 *>(rgb_out_device0), rows[r], static_cast<int>(row_floats / 4), r, n);
+    } else {
+      const size_t count = static_cast<size_t>(rows[r]) * row_floats;
+      hipLaunchKernelGGL(k_place_rows_scalar, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, s0, src, rgb_out_device0, rows[r],
+                         static_cast<int>(row_floats), r, n);
+    }
+    RT_HIP(hipGetLastError());
+  }
+  // 3. the frame is complete when rank 0's stream is idle; the other streams only have their sends left
+  for (int r = 0; r < n; ++r)
+    if (rows[r])
+      RT_HIP(hipEventSynchronize(m->done[r]));
+  const auto all_rendered = std::chrono::steady_clock::now();
+  for (int r = n - 1; r >= 0; --r) {
+    RT_ON_DEVICE(m->devices[r]);
+    RT_HIP(hipStreamSynchronize(m->streams[r]));
+  }
+  // what the gather adds to the frame: from the moment the last rank finished rendering to the assembled frame
+  const float gather_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - all_rendered).count();
+  if (stats || timing) {
+    if (stats)
+      std::memset(stats, 0, sizeof *stats);
+    if (timing)
+      std::memset(timing, 0, sizeof *timing);
+    float slowest = 0.f;
+    uint64_t rays_total = 0, capped_total = 0, samples_total = 0;
+    for (int r = 0; r < n; ++r) {
+      if (!rows[r])
+        continue;
+      RT_ON_DEVICE(m->devices[r]);
+      uint64_t rays = 0, capped = 0;
+      if (rt_status st = read_tallies(info[r].counters, &rays, &capped))
+        return st;
+      float ms = 0.f;
+      RT_HIP(hipEventElapsedTime(&ms, m->begun[r], m->done[r]));
+      slowest = std::max(slowest, ms);
+      rays_total += rays, capped_total += capped, samples_total += info[r].n_samples;
+      if (timing && r < RT_MULTI_MAX_TIMED_RANKS)
+        timing->render_ms[r] = ms, timing->rays[r] = rays;
+    }
+    if (stats) {
+      stats->rays = rays_total, stats->capped_samples = capped_total, stats->samples = samples_total, stats->kernel_ms = slowest;
+      stats->grid = info[0].grid, stats->block = info[0].block;
+      std::memcpy(stats->kernel, info[0].kernel, sizeof stats->kernel);
+    }
+    if (timing)
+      timing->n_ranks = n, timing->slowest_render_ms = slowest, timing->gather_ms = gather_ms;
+  }
+  return RT_OK;
+}
+
+rt_status rt_multi_render_host(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, rt_stats *stats,
+                               rt_multi_timing *timing) {
+  if (!m || !cfg || !rgb_out_host)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_host: NULL argument");
+  if (rt_status st = check_cfg(cfg))
+    return st;
+  RT_ON_DEVICE(m->devices[0]);
+  const size_t bytes = static_cast<size_t>(cfg->height) * cfg->width * 3 * sizeof(float);
+  if (rt_status st = ensure(m->frame, bytes))
+    return st;
+  if (rt_status st = rt_multi_render(m, cam, cfg, static_cast<float *>(m->frame.ptr), stats, timing))
+    return st;
+  RT_HIP(hipMemcpy(rgb_out_host, m->frame.ptr, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
 }
 
 rt_status rt_trace_rays(rt_scene *sc, const rt_ray *rays, size_t n, rt_hit *hits) {

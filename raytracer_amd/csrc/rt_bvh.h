@@ -157,7 +157,7 @@ struct BvhStats {};
 // and refresh their pruning bound from it.  No counters are needed: the wave leaves when none of its lanes has work,
 // and then every key is final.
 template <bool FAST, bool SPLIT, bool LEAF_LDS>
-RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray &own_ray, bool active, unsigned long long *res,
+RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray &own_ray, int own_self_pos, bool active, unsigned long long *res,
                                int *donor_lane, BvhStats &st) {
   extern __shared__ uint4 bvh_lds[];
   const int lds_nodes = p.bvh_lds_nodes;
@@ -172,6 +172,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
   float a = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
   float inv_a = 1.f / a;
   int owner = lane;
+  int self_pos = own_self_pos; // leaf position of the sphere the ray leaves (FAST: not tested here, see self_sphere_exact); -1: none
   float bt = INF_F;
   int n = 1, level = 0;
   uint32_t trail = 0; // bit L: the sibling of this path's node at level L is still to be visited
@@ -205,6 +206,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
         __builtin_amdgcn_wave_barrier();
         const int src = is_thief ? *reinterpret_cast<volatile int *>(donor_lane + idle_rank) : lane;
         const int g_node = __shfl(give_node, src, 64), g_level = __shfl(give_level, src, 64), g_owner = __shfl(owner, src, 64);
+        const int g_self = __shfl(self_pos, src, 64);
         const float g_bt = __shfl(bt, src, 64), g_tmin = __shfl(tmin, src, 64), g_a = __shfl(a, src, 64), g_inv_a = __shfl(inv_a, src, 64);
         const V3 g_o = mk3(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
         const V3 g_d = mk3(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
@@ -218,6 +220,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
           br.ry = (int)((__float_as_uint(g_id.y) >> 31) << 4);
           br.rz = (int)((__float_as_uint(g_id.z) >> 31) << 4);
           owner = g_owner;
+          self_pos = g_self;
           bt = g_bt;
           n = g_node, level = g_level, trail = 0u;
           cur = bvh_fetch<SPLIT>(s, lds_nodes, n);
@@ -311,7 +314,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
             t = t2;
             ok = t2 > tmin; // tmax = inf for every ray of the path kernels
           }
-          if (ok && t <= bt)
+          if (ok && t <= bt && first + min(k, count - 1) != self_pos)
             bvh_accept(s, slot, first + min(k, count - 1), t, bt);
         }
       } else {
@@ -320,7 +323,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
         for (int k = 0; k < count; ++k) {
           float t;
           const bool hit = FAST ? bvh_gen_front_t(s.bvh_recs[first + k].inv, ray, t) : sphere_front_t(s.bvh_recs[first + k].inv, ray, t);
-          if (hit && t <= bt)
+          if (hit && t <= bt && first + k != self_pos)
             bvh_accept(s, slot, first + k, t, bt);
         }
       }
@@ -349,7 +352,9 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
   B.init(p, sh); // synchronises the workgroup
   BvhStats st{};
   while (B.deal(s, p, sh)) {
-    bvh_closest_sphere<FAST, SPLIT, LEAF_LDS>(s, p, B.ray, B.active, res, donor_lane, st);
+    // FAST: the sphere a ray leaves is kept out of the fused tests and tested with the reference's arithmetic below
+    const int self_pos = FAST && B.active && B.origin_shape >= 0 ? s.shape_origin[4 * B.origin_shape + 2] : -1;
+    bvh_closest_sphere<FAST, SPLIT, LEAF_LDS>(s, p, B.ray, self_pos, B.active, res, donor_lane, st);
     Hit h;
     h.object = h.shape = -1;
     h.t = 0.f;
@@ -375,11 +380,13 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
         one.t = INF_F;
         one.object = 0x7fffffff;
         one.shape = -1;
-        sphere_scan_test<FAST>(rec, B.ray, one);
+        sphere_scan_test<FAST>(rec, B.ray, one, FAST ? B.origin_shape : -2);
         if (one.shape >= 0 && (one.t < best.t || (one.t == best.t && one.object < best.object)))
           best = one;
       }
-      h = world_finish_hit<FAST>(s, B.ray, best, &fetch);
+      if (FAST)
+        self_sphere_exact(s, B.origin_shape, B.ray, best);
+      h = world_finish_hit<FAST, true>(s, B.ray, best, &fetch);
     }
     B.shade(s, p, sh, h, &fetch);
   }

@@ -617,7 +617,8 @@ struct Best {
 //  FAST == true : the same quantities with fused multiply-adds and one reciprocal (path mode, whose
 //                 parity bar is statistical): 33 VALU instructions up to the discriminant test
 //                 instead of 52 flops unfused.  a > 0 and sqrt > 0 give t1 < t2 without the swap.
-template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &ray, Best &best) {
+// skip_shape (FAST only): the sphere the ray leaves is not tested here but by self_sphere_exact below.
+template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &ray, Best &best, int skip_shape = -2) {
   if (FAST) {
     const RecRegs &m = r;
     const float dx = fmaf(m[0], ray.d.x, fmaf(m[1], ray.d.y, m[2] * ray.d.z));
@@ -641,7 +642,7 @@ template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &r
         t = t2;
         ok = t2 > ray.tmin && t2 < ray.tmax;
       }
-      if (ok && t < best.t) {
+      if (ok && t < best.t && r.shape() != skip_shape) {
         best.t = t;
         best.object = r.object();
         best.shape = r.shape();
@@ -660,19 +661,44 @@ template <bool FAST> RT_DEV void sphere_scan_test(const RecRegs &r, const Ray &r
 // The scan over the top-level spheres, in World::objects order (strict `<`: the lowest index wins
 // ties).  Records ping-pong between two SGPR sets so that the scalar load of the next record is in
 // flight while the lanes test the current one.
-template <bool FAST> RT_DEV void scan_spheres(const ScanRec *recs, int n, const Ray &ray, Best &best) {
+template <bool FAST> RT_DEV void scan_spheres(const ScanRec *recs, int n, const Ray &ray, Best &best, int skip_shape = -2) {
   if (n <= 0)
     return;
   RecRegs a = load_rec(recs, 0);
   int i = 0;
   for (; i + 1 < n; i += 2) {
     const RecRegs b = load_rec(recs, i + 1);
-    sphere_scan_test<FAST>(a, ray, best);
+    sphere_scan_test<FAST>(a, ray, best, skip_shape);
     a = load_rec(recs, min(i + 2, n - 1));
-    sphere_scan_test<FAST>(b, ray, best);
+    sphere_scan_test<FAST>(b, ray, best, skip_shape);
   }
   if (i < n)
-    sphere_scan_test<FAST>(a, ray, best);
+    sphere_scan_test<FAST>(a, ray, best, skip_shape);
+}
+
+// The sphere a ray LEAVES is the one sphere whose test decides something systematic: a mirror ray (tmin = 1e-5) starts a
+// rounding error away from the surface, and whether it finds the exit root of its own sphere beyond tmin is, in the
+// reference's arithmetic, close to a coin flip for small far spheres (the root cancels ~4 digits: the reference re-hits on
+// 22 % of the reflections off the 0.05-0.15 spheres of the synthetic scenes).  Each such re-hit costs a factor rho, so an
+// arithmetic with another error distribution shifts the image: the fused world-space test renders the 4096-sphere scene
+// 0.7 % brighter than the reference's own render (9 standard errors), the unfused kernel does not.  So the fused scans of
+// the large-world kernels leave that one sphere out, and it is tested here with the reference's operation order — once
+// per ray, against thousands of fused tests.
+RT_DEV void self_sphere_exact(const Scene &s, int self_shape, const Ray &ray, Best &best) {
+#ifdef RT_NO_SELF_EXACT
+  return;
+#endif
+  if (self_shape < 0)
+    return;
+  const int4 org = reinterpret_cast<const int4 *>(s.shape_origin)[self_shape];
+  if (!(org.w & 1))
+    return; // a plane or a CSG leaf: tested by world_finish_hit
+  float t;
+  if (sphere_front_t(s.shape_inv + 12 * self_shape, ray, t) && (t < best.t || (t == best.t && org.x < best.object))) {
+    best.t = t;
+    best.object = org.x;
+    best.shape = self_shape;
+  }
 }
 
 // Second half of World::ray_intersection (shapes.hpp:547-561) once the spheres have been scanned:
@@ -684,7 +710,11 @@ struct ShadeFetch {
   bool have;
 };
 
-template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
+// EXACT_RECORD (the large-world FMA kernels): the fused scan only FINDS the winner; when it is a top-level sphere its t
+// and its hit record are recomputed with the reference's unfused operation order, so that the point the next ray starts
+// from carries the reference's rounding-error distribution (see self_sphere_exact: the brightness of a crowded scene
+// depends on it).
+template <bool FAST, bool EXACT_RECORD = false> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
   if (fetch)
     fetch->have = false;
   for (int i = 0; i < s.n_planes; ++i) {
@@ -738,7 +768,13 @@ template <bool FAST> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray,
       fetch->r0 = rec[0], fetch->r1 = rec[1];
       fetch->have = true;
     }
-    if (FAST) {
+    if (FAST && EXACT_RECORD && s.shape_kind[best.shape] == RT_SHAPE_SPHERE) {
+      Ray local = ray_transform(ray, s.shape_inv + 12 * best.shape);
+      float t_ref, t_far;
+      if (solve_ray_sphere(local, t_ref, t_far) > 0) // a grazing winner the unfused test misses keeps the fused t
+        h.t = t_ref;
+      make_hit(s, best.shape, local, h.t, h.point, h.normal, h.local);
+    } else if (FAST) {
       make_hit_fast(s, best.shape, ray, best.t, h.point, h.normal, h.local);
     } else {
       Ray local = ray_transform(ray, s.shape_inv + 12 * best.shape);

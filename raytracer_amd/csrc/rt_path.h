@@ -82,7 +82,7 @@ RT_DEV void wave_add_tally(unsigned long long *counters, int which, unsigned lon
 // deeper node is used up, hence at most T nodes per depth level: capacity T * max_depth (T if n_rays
 // is 1, where a node is used up by the one lane that takes it).
 // ---------------------------------------------------------------------------------------------
-constexpr int NODE_WORDS = 13; // point(3) vec(3) weight(3) key(2) meta(1) remaining(1)
+constexpr int NODE_WORDS = 14; // point(3) vec(3) weight(3) key(2) meta(1) remaining(1) shape-hit(1)
 constexpr int SAMPLE_CHUNK = 2; // pixel samples fetched from the call's queue per top-up, in units of T
 
 RT_DEV uint64_t node_child_key(uint64_t parent_state, uint32_t k) { // same in oracle/rt_oracle.c
@@ -146,6 +146,7 @@ template <int T, bool FAST> struct PathBlock {
   Pcg pcg; // this ray's own stream (already past its scatter draws)
   V3 throughput;
   int depth, slot;
+  int origin_shape; // the shape this ray leaves (-1: a camera ray)
   // workgroup state mirrored in every lane (uniform)
   int top;
   uint32_t rays;
@@ -161,6 +162,7 @@ template <int T, bool FAST> struct PathBlock {
     pcg.inc = (p.seq_number << 1u) | 1u;
     throughput = mk3(1.f, 1.f, 1.f);
     depth = slot = 0;
+    origin_shape = -1;
     top = 0;
     rays = 0;
     cap = p.pool_cap;
@@ -248,6 +250,7 @@ template <int T, bool FAST> struct PathBlock {
       ray.o = mk3(node_word(0, node), node_word(1, node), node_word(2, node));
       const V3 vec = mk3(node_word(3, node), node_word(4, node), node_word(5, node));
       throughput = mk3(node_word(6, node), node_word(7, node), node_word(8, node));
+      origin_shape = __float_as_int(node_word(13, node));
       if (meta >> 31) { // SpecularBRDF: every child is the mirror ray, no draw
         ray.d = vec;
         ray.tmin = 1.e-5f;
@@ -272,6 +275,7 @@ template <int T, bool FAST> struct PathBlock {
       ray = primary_ray(p, sid);
       pcg.state = node_root_key(p.seq_number, sid.global);
       depth = 0;
+      origin_shape = -1;
       throughput = mk3(1.f, 1.f, 1.f);
       active = true;
     }
@@ -377,6 +381,7 @@ template <int T, bool FAST> struct PathBlock {
       node_word(9, node) = __uint_as_float((uint32_t)pcg.state);
       node_word(10, node) = __uint_as_float((uint32_t)(pcg.state >> 32));
       node_word(11, node) = __uint_as_float((uint32_t)slot | ((uint32_t)(depth + 1) << 16) | ((uint32_t)brdf << 31));
+      node_word(13, node) = __int_as_float(h.shape);
       set_rem(sh, node, p.n_rays);
     }
     top += n_push;

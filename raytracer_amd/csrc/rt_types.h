@@ -96,6 +96,9 @@ struct Scene {
   const uint8_t *shape_kind;
   const uint32_t *shape_material;
   const ShadeRec *shape_shade;
+  // per shape: {index in World::objects (-1: a CSG leaf), position in wide_recs (-1: none), position in bvh_recs (-1: none),
+  // bit 0: top-level sphere} — what a ray needs to know about the sphere it LEAVES (rt_device.h self_sphere_exact)
+  const int32_t *shape_origin;    // [n_shapes][4]
   // world <-> shape-local transforms with the CSG ancestors' transforms folded in (== shape_inv / shape_fwd for a
   // top-level shape): what the FMA path kernels use instead of walking the chain of nodes
   const float *shape_w2l;         // [n_shapes][12]

@@ -31,7 +31,9 @@ namespace rtd {
 struct alignas(16) WideRay { // LDS image of one queued ray: 3 x 16 bytes
   float ox, oy, oz, tmin;
   float dx, dy, dz, tmax;
-  float a, inv_a, pad0, pad1; // D.D and its reciprocal
+  float a, inv_a;             // D.D and its reciprocal
+  int self;                   // position in the register rows of the sphere the ray leaves (-1: none): left to self_sphere_exact
+  float pad1;
 };
 
 template <bool ISO, int K> struct WideSlots;
@@ -109,9 +111,10 @@ RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRay &r, unsigned l
   if (dmax > 0.f) {
     float best_t = INF_F;
     int best_k = -1;
+    const int self_rel = r.self - first - wave * 64 - lane; // == k * W * 64 for the row that holds the ray's own sphere
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (disc[k] > 0.f) {
+      if (disc[k] > 0.f && self_rel != k * W * 64) {
         float inv_a;
         slots.a_of(k, r, inv_a);
         const float sq = sqrtf(disc[k]);
@@ -185,7 +188,11 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       r.dx = L.ray.d.x, r.dy = L.ray.d.y, r.dz = L.ray.d.z, r.tmax = L.ray.tmax;
       r.a = fmaf(r.dx, r.dx, fmaf(r.dy, r.dy, r.dz * r.dz));
       r.inv_a = 1.f / r.a;
-      r.pad0 = r.pad1 = 0.f;
+      r.self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
+#ifdef RT_NO_SELF_EXACT
+      r.self = -1;
+#endif
+      r.pad1 = 0.f;
       q_ray[my_q] = r;
       q_key[my_q] = ~0ull;
     }
@@ -229,7 +236,12 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       best.t = INF_F;
       best.object = 0x7fffffff;
       best.shape = -1;
-      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best); // in object order: strict `<` among them
+#ifdef RT_NO_SELF_EXACT
+      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best);
+#else
+      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best, L.origin_shape); // in object order: strict `<` among them
+#endif
+      self_sphere_exact(s, L.origin_shape, L.ray, best);
       if (key != ~0ull && (unsigned)(key & 0xffffffffull) < (unsigned)s.n_wide) { // positions in the register rows ascend with the object index: the key's tie-break is the reference's
         const int2 ids = *reinterpret_cast<const int2 *>(&s.wide_recs[(int)(unsigned)(key & 0xffffffffull)].object); // {object, shape}
         const float t = __uint_as_float((unsigned)(key >> 32));
@@ -239,7 +251,7 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
           best.shape = ids.y;
         }
       }
-      h = world_finish_hit<true>(s, L.ray, best);
+      h = world_finish_hit<true, true>(s, L.ray, best);
     }
     L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
 #ifdef RT_PROFILE_PHASES

@@ -106,6 +106,40 @@ class DeviceWorld:
         return vis
 
 
+class MultiDeviceWorld:
+    """One replica of a flattened World per GPU of the node (rt_multi*): the frame's rows are dealt round-robin to the
+    devices and gathered on the first one with RCCL (peer copies when ranks share a device or peer_copies=True)."""
+
+    def __init__(self, scene: FlatScene, devices=None, peer_copies: bool = False, rccl_self: bool = False):
+        self.scene = scene
+        devices = list(devices) if devices is not None else []
+        self._handle = C.c_void_p()
+        desc = scene.desc()
+        arr = (C.c_int * max(len(devices), 1))(*devices)
+        flags = (abi.RT_MULTI_PEER_COPIES if peer_copies else 0) | (abi.RT_MULTI_RCCL_SELF if rccl_self else 0)
+        check(dll().rt_multi_create(C.byref(desc), arr, len(devices), flags, C.byref(self._handle)))
+        self.n_ranks = dll().rt_multi_rank_count(self._handle)
+        self.uses_rccl = bool(dll().rt_multi_uses_rccl(self._handle))
+        self.first_device = devices[0] if devices else 0
+
+    def close(self):
+        if self._handle:
+            dll().rt_multi_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._handle:
+            raise RuntimeError("MultiDeviceWorld is closed")
+        return self._handle
+
+
 def aa_jitter(sample_index, device: int = 0):
     k = np.ascontiguousarray(sample_index, dtype=np.uint64)
     u = np.zeros(len(k), dtype=np.float32)
@@ -183,6 +217,39 @@ class GpuImageTracer:
         check(dll().rt_render(world.handle, C.byref(cam), C.byref(cfg), out.data_ptr(), stream, stats_p))
         self.last_stats = stats if want_stats else None
         return out
+
+
+    def fire_all_rays_multi(self, world: MultiDeviceWorld, mode: RenderMode, out=None):
+        """The whole frame on every device of `world`.  out=None -> numpy [H, W, 3]; out=<tensor on the first device> stays
+        in HBM.  Sets last_stats (summed over ranks) and last_timing (abi.rt_multi_timing)."""
+        cfg = self.make_cfg(mode)
+        cam = self.camera.to_abi()
+        stats, timing = abi.rt_stats(), abi.rt_multi_timing()
+        if out is None:
+            img = np.empty((self.height, self.width, 3), dtype=np.float32)
+            check(dll().rt_multi_render_host(world.handle, C.byref(cam), C.byref(cfg), img.ctypes.data, C.byref(stats), C.byref(timing)))
+        else:
+            import torch
+            if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (self.height, self.width, 3)
+                    and out.device.index == world.first_device):
+                raise ValueError("out must be a contiguous float32 CUDA tensor [H, W, 3] on the first device of the world")
+            check(dll().rt_multi_render(world.handle, C.byref(cam), C.byref(cfg), out.data_ptr(), C.byref(stats), C.byref(timing)))
+            img = out
+        self.last_stats, self.last_timing = stats, timing
+        return img
+
+    def fire_all_rays_host(self, world: DeviceWorld, mode: RenderMode, n_slices: int = 8, progress=None):
+        """rt_render_frame_host: the frame into host memory with the reference's progress callback (values in (0, 1])."""
+        cfg = self.make_cfg(mode)
+        cam = self.camera.to_abi()
+        stats = abi.rt_stats()
+        img = np.empty((self.height, self.width, 3), dtype=np.float32)
+        cb_type = C.CFUNCTYPE(None, C.c_float, C.c_void_p)
+        cb = cb_type((lambda f, _u: progress(f)) if progress else 0)
+        check(dll().rt_render_frame_host(world.handle, C.byref(cam), C.byref(cfg), img.ctypes.data, n_slices,
+                                         C.cast(cb, C.c_void_p) if progress else None, None, C.byref(stats)))
+        self.last_stats = stats
+        return img
 
 
 # -- the tone-mapping tail (reference src/raytracer.cpp:176-186, include/colors.hpp:469-516) -------------------------

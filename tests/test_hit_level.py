@@ -121,8 +121,11 @@ def test_fast_scans_pick_the_reference_winner(n):
         # reference's arithmetic that is common for small far spheres — the root t = (-b - sqrt(b^2 - ac)) / a cancels
         # ~4 digits, the hit point is off by ~1e-4 radii along the ray and the exit root of the mirror ray lands right
         # at tmin = 1e-5: the oracle itself re-hits on 22 % of the reflections off the small spheres here (11 % of all
-        # pixels).  Which side of tmin it falls is a last-bit matter, so those flips are counted apart from the rest.
+        # pixels).  Which side of tmin it falls is a last-bit matter — and the brightness of a crowded scene depends on it
+        # (each re-hit costs a factor rho) — which is why the large-world kernels recompute the winner's hit record and
+        # test the sphere a ray leaves in the reference's own operation order (rt_device.h self_sphere_exact): with that
+        # the fused kernels reproduce these decisions too (measured: 0-1 flips of 20 736; 900-2 700 before).
         second = (got2 != ref2) & (got1 == ref1)
         self_hit = second & ((got2 == got1) | (ref2 == ref1))
         print(f"  of the second-hit differences {int(self_hit.sum())} are own-sphere re-hits on one side")
-        assert (second & ~self_hit).mean() <= 0.01 and self_hit.mean() <= 0.25
+        assert (second & ~self_hit).mean() <= 0.005 and self_hit.mean() <= 0.01

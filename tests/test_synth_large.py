@@ -1,0 +1,78 @@
+"""The LARGE synthetic worlds (512 and 4096 random spheres + floor + sky: the scenes of BASELINE.json's headline metric)
+against renders made by the UNMODIFIED reference (tests/golden/synth_large_images.npz, written by
+tests/golden/make_synth_large_golden.py running oracle/_ref/rt_ref on the scene text raytracer_amd/synth.py emits;
+the 4096-sphere path render alone is 48 minutes of the reference's CPU time).
+
+  * flat renders (every object tested per ray, no randomness): the CPU oracle and the GPU reproduce the reference
+    bit for bit, 4098 objects included;
+  * path 10/3/5 renders: the reference consumes ONE serial PCG, the device gives every ray its own stream, so the
+    comparison is statistical: the default kernels for these worlds — the fused wide kernel, world-space sphere form,
+    K = 8 register rows, W = 1 wave (N = 512) and W = 8 waves (N = 4096) — rendered with four seeds against the
+    reference's single render: image mean within 4 standard errors (measured from the seeds) AND within 1.5 %, and the
+    per-pixel difference within the seeds' own spread for > 95 % of the pixels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd.synth import synthetic_scene
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ref_images():
+    return dict(np.load(os.path.join(GOLDEN, "synth_large_images.npz")))
+
+
+@pytest.fixture(scope="module")
+def big_scenes():
+    return {n: synthetic_scene(n)[0] for n in (512, 4096)}
+
+
+@pytest.mark.parametrize("n", [512, 4096])
+def test_oracle_flat_equals_reference(ref_images, big_scenes, n):
+    img, stats = O.render(big_scenes[n], O.make_cfg(160, 90, "flat", spp_edge=1))
+    assert np.array_equal(img, ref_images[f"flat_synth{n}_160x90_aa1"])
+    assert stats.rays == 160 * 90
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 4096])
+def test_gpu_flat_equals_reference(ref_images, big_scenes, n):
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    world = DeviceWorld(big_scenes[n])
+    img = GpuImageTracer(160, 90, big_scenes[n].camera, 1).fire_all_rays(world, RenderMode("flat"))
+    world.close()
+    assert np.array_equal(img, ref_images[f"flat_synth{n}_160x90_aa1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,w,h,kernel", [(512, 128, 72, "k_render_path_wide<ISO,K=8,W=1>"), (4096, 48, 27, "k_render_path_wide<ISO,K=8,W=8>")])
+def test_gpu_wide_kernel_converges_to_reference_render(ref_images, big_scenes, n, w, h, kernel):
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    scene = big_scenes[n]
+    world = DeviceWorld(scene)
+    tr = GpuImageTracer(w, h, scene.camera, 2)
+    imgs = []
+    for seed in (54, 55, 56, 57):
+        imgs.append(tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=seed)))
+        assert tr.last_stats.kernel.decode() == kernel  # the kernel BASELINE's configs run on
+    bvh = tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=58, bvh=True))
+    world.close()
+    ref = ref_images[f"path_synth{n}_{w}x{h}_aa2_serial"].astype(np.float64)
+    stack = np.stack(imgs).astype(np.float64)
+    means = stack.mean(axis=(1, 2, 3))
+    se = means.std(ddof=1) * np.sqrt(1 + 1 / 4)  # (mean of 4 seeds) - (one independent render)
+    diff = means.mean() - ref.mean()
+    print(f"n={n}: reference mean {ref.mean():.5f}, device {means.mean():.5f} (seeds {np.round(means, 5)}), diff {diff:+.5f} = {diff / se:+.2f} s.e. = "
+          f"{100 * diff / ref.mean():+.2f} %")
+    assert abs(diff) <= 4 * se and abs(diff) <= 0.015 * ref.mean()
+    mean, spread = stack.mean(0), stack.std(0, ddof=1)
+    z = np.abs(mean - ref) / (spread * np.sqrt(1 + 1 / 4) + 2e-2)
+    print(f"n={n}: per-pixel z < 4 on {100 * np.mean(z < 4.0):.2f} % of components")
+    assert np.mean(z < 4.0) > 0.95
+    # the optional BVH mode on the same world: another seed of the same estimator
+    assert abs(bvh.astype(np.float64).mean() - ref.mean()) <= 5 * means.std(ddof=1) * np.sqrt(2) + 0.015 * ref.mean()
