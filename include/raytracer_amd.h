@@ -270,9 +270,11 @@ RT_API rt_status rt_render_host(rt_scene *scene, const rt_camera *camera, const 
                          float *rgb_out_host, rt_stats *stats);
 
 /* The whole fire_all_rays call into host memory, with its progress callback: ImageTracer::fire_all_rays(func, callback)
- * (include/cameras.hpp:221-251) reports (col + 1) / W after every column (cameras.hpp:249); here the frame is rendered
- * as n_slices horizontal slices queued back to back on one stream, `progress` is called with rows_done / height in
- * (0, 1] as each finishes, and ONE device-to-host copy delivers HdrImage::pixels at the end.  The framebuffer in HBM
+ * (include/cameras.hpp:221-251) reports (col + 1) / W after every column (cameras.hpp:249); here `progress` is called
+ * at most n_slices times with increasing values in (0, 1], the last one 1 — the deterministic modes render n_slices
+ * horizontal slices queued back to back on one stream and report rows_done / height as each finishes, path mode is one
+ * launch whose sample queue is watched from a second stream (fraction of the frame's samples handed out) — and ONE
+ * device-to-host copy delivers HdrImage::pixels at the end.  The framebuffer in HBM
  * belongs to the scene handle and is reused from frame to frame (no allocation per frame once it is large enough).
  * cfg must describe the whole image.  progress may be NULL (then the frame is one launch). */
 typedef void (*rt_progress_fn)(float fraction_done, void *user);

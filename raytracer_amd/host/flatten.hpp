@@ -23,6 +23,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <cstring>
 #include <vector>
 
 namespace raytracer_amd {
@@ -80,6 +81,21 @@ struct FlatScene {
     d.light_color = light_color.data();
     d.light_radius = light_radius.data();
     return d;
+  }
+
+  /// Bit-for-bit equality of two flattened Worlds (the signs of zeros matter to copysign: values are not enough).
+  bool same_bits(const FlatScene &o) const {
+    auto eq = [](const auto &a, const auto &b) {
+      return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+    };
+    return eq(shape_kind, o.shape_kind) && eq(shape_material, o.shape_material) && eq(shape_fwd, o.shape_fwd) && eq(shape_inv, o.shape_inv) &&
+           eq(csg_op, o.csg_op) && eq(csg_left, o.csg_left) && eq(csg_right, o.csg_right) && eq(csg_fwd, o.csg_fwd) && eq(csg_inv, o.csg_inv) &&
+           eq(objects, o.objects) && eq(material_brdf, o.material_brdf) && eq(material_brdf_pigment, o.material_brdf_pigment) &&
+           eq(material_emission_pigment, o.material_emission_pigment) && eq(pigment_kind, o.pigment_kind) &&
+           eq(pigment_color1, o.pigment_color1) && eq(pigment_color2, o.pigment_color2) && eq(pigment_n_intervals, o.pigment_n_intervals) &&
+           eq(pigment_tex_offset, o.pigment_tex_offset) && eq(pigment_tex_width, o.pigment_tex_width) &&
+           eq(pigment_tex_height, o.pigment_tex_height) && eq(texels, o.texels) && eq(light_point, o.light_point) &&
+           eq(light_color, o.light_color) && eq(light_radius, o.light_radius);
   }
 };
 

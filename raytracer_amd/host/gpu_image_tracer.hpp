@@ -57,8 +57,10 @@ public:
   std::unique_ptr<HdrImage> image;
   std::shared_ptr<Camera> camera;
   int samples_per_pixel_edge;
-  int device = 0;
+  int device = 0;            ///< the GPU of a single-device render
+  bool all_devices = true;   ///< more than one GPU visible: deal the frame's rows to all of them (rt_multi_*, RCCL gather)
   rt_stats last_stats{};
+  rt_multi_timing last_timing{}; ///< multi-GPU renders: per-rank kernel time and the gather
 
   using ProgressCallback = std::function<void(float)>;
 
@@ -68,15 +70,31 @@ public:
     if (!this->camera->asp_ratio.has_value())
       this->camera->asp_ratio.emplace(static_cast<float>(this->image->width) / static_cast<float>(this->image->height));
   }
+  GpuImageTracer(const GpuImageTracer &) = delete;
+  GpuImageTracer &operator=(const GpuImageTracer &) = delete;
+  ~GpuImageTracer() { release(); }
 
   /// Replaces ImageTracer::fire_all_rays (include/cameras.hpp:221-251) + Renderer::operator().
-  /// The image is rendered in `progress_bands` horizontal slices so that progress can be reported.
+  ///
+  /// The flattened World stays resident in HBM between calls: it is uploaded again only when the World's flattened
+  /// arrays change (an animation changes the camera, not the World), and the frame lives in a device buffer the
+  /// library reuses.  One GPU: the image is rendered as `progress_slices` horizontal slices queued back to back, the
+  /// callback is invoked with rows_done / height as each finishes (the reference reports once per column), and one
+  /// device-to-host copy fills HdrImage::pixels.  Several GPUs: the rows are dealt round-robin to all of them and
+  /// gathered over RCCL; progress is reported once, at the end.
   void fire_all_rays(const World &world, const GpuRenderMode &mode, ProgressCallback report_progress = [](float) {},
-                     int progress_bands = 8) {
+                     int progress_slices = 8) {
     FlatScene flat = flatten_world(world);
-    rt_scene_desc desc = flat.desc();
-    rt_scene *scene = nullptr;
-    check(rt_scene_create(&desc, device, &scene));
+    const bool want_multi = all_devices && rt_device_count() > 1;
+    if (!(scene_ || multi_) || want_multi != (multi_ != nullptr) || !flat.same_bits(resident_)) {
+      release();
+      rt_scene_desc desc = flat.desc();
+      if (want_multi)
+        check(rt_multi_create(&desc, nullptr, 0, 0, &multi_));
+      else
+        check(rt_scene_create(&desc, device, &scene_));
+      resident_ = std::move(flat);
+    }
     const rt_camera cam = flatten_camera(*camera);
     rt_render_cfg cfg{};
     cfg.width = image->width, cfg.height = image->height, cfg.spp_edge = samples_per_pixel_edge;
@@ -88,32 +106,34 @@ public:
     cfg.max_mirror_bounces = mode.max_mirror_bounces;
     cfg.flags = mode.flags;
     cfg.rng_mode = RT_RNG_PER_NODE_STREAMS;
+    cfg.band_rows = cfg.band_stride = cfg.n_local_rows = image->height, cfg.band_offset = 0; // the whole image
     static_assert(sizeof(Color) == 3 * sizeof(float), "HdrImage::pixels must be packed rgb floats");
     float *pixels = reinterpret_cast<float *>(image->pixels.data());
     last_stats = rt_stats{};
-    const int H = image->height;
-    const int bands = std::max(1, std::min(progress_bands, H));
-    for (int b = 0; b < bands; ++b) {
-      const int row0 = static_cast<int>(static_cast<long long>(H) * b / bands);
-      const int row1 = static_cast<int>(static_cast<long long>(H) * (b + 1) / bands);
-      if (row1 == row0)
-        continue;
-      cfg.band_rows = row1 - row0, cfg.band_stride = H, cfg.band_offset = row0, cfg.n_local_rows = row1 - row0;
-      rt_stats st{};
-      rt_status rc = rt_render_host(scene, &cam, &cfg, pixels + static_cast<size_t>(row0) * image->width * 3, &st);
-      if (rc != RT_OK) {
-        std::string msg = rt_last_error();
-        rt_scene_destroy(scene);
-        throw std::runtime_error("raytracer_amd: " + msg);
-      }
-      last_stats.rays += st.rays, last_stats.samples += st.samples, last_stats.capped_samples += st.capped_samples;
-      last_stats.kernel_ms += st.kernel_ms;
-      report_progress(static_cast<float>(row1) / static_cast<float>(H));
+    last_timing = rt_multi_timing{};
+    if (multi_) {
+      check(rt_multi_render_host(multi_, &cam, &cfg, pixels, &last_stats, &last_timing));
+      report_progress(1.f);
+    } else {
+      auto trampoline = [](float fraction, void *user) { (*static_cast<ProgressCallback *>(user))(fraction); };
+      check(rt_render_frame_host(scene_, &cam, &cfg, pixels, progress_slices, trampoline, &report_progress, &last_stats));
     }
-    rt_scene_destroy(scene);
+  }
+
+  /// Frees the resident World (the destructor does it too).
+  void release() {
+    if (scene_)
+      rt_scene_destroy(scene_);
+    if (multi_)
+      rt_multi_destroy(multi_);
+    scene_ = nullptr, multi_ = nullptr;
   }
 
 private:
+  rt_scene *scene_ = nullptr;
+  rt_multi *multi_ = nullptr;
+  FlatScene resident_; // what the handle above was created from
+
   static void check(rt_status rc) {
     if (rc != RT_OK)
       throw std::runtime_error(std::string("raytracer_amd: ") + rt_last_error());

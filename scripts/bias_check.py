@@ -1,19 +1,36 @@
-import sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-from raytracer_amd.synth import synthetic_scene
-from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
-ref = dict(np.load('/root/repo/tests/golden/synth_large_images.npz'))
-for n, w, h in ((4096, 48, 27), (512, 128, 72)):
-    scene = synthetic_scene(n)[0]
+#!/usr/bin/env python3
+"""Does a fused (FMA) path kernel render the same EXPECTED image as the unfused one (= the reference's arithmetic)?
+Image means over several seeds, per kernel variant, with their standard errors.
+
+    python scripts/bias_check.py synth:4096:48x27 synth:512:128x72 scene:demo_path:320x240 scene:csg_example:320x180
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd.scene import FlatScene  # noqa: E402
+from raytracer_amd.synth import synthetic_scene  # noqa: E402
+from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode  # noqa: E402
+
+for spec in sys.argv[1:]:
+    kind, name, size = spec.split(":")
+    w, h = map(int, size.split("x"))
+    scene = synthetic_scene(int(name))[0] if kind == "synth" else FlatScene.from_json(os.path.join(ROOT, "tests", "golden", f"{name}.scene.json"))
     world = DeviceWorld(scene)
     tr = GpuImageTracer(w, h, scene.camera, 2)
-    r = ref[f"path_synth{n}_{w}x{h}_aa2_serial"].astype(np.float64)
-    print(n, "reference mean", r.mean(), "per channel", r.mean(axis=(0, 1)))
-    for name, kw in (("wide", {}),):
+    print(spec, flush=True)
+    variants = [("default", {}), ("exact", dict(exact=True))]
+    if kind == "synth":
+        variants += [("objspace", dict(object_space_spheres=True)), ("bvh", dict(bvh=True))]
+    for label, kw in variants:
         ms, rays = [], []
-        for seed in range(100, 106):
+        for seed in range(100, 108):
             img = tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=seed, **kw)).astype(np.float64)
-            ms.append(img.mean()); rays.append(int(tr.last_stats.rays))
+            ms.append(img.mean())
+            rays.append(int(tr.last_stats.rays))
         ms = np.array(ms)
-        print(f"  {name:10s}", flush=True) if False else print(f"  {name:10s} mean {ms.mean():.5f} +- {ms.std(ddof=1) / np.sqrt(len(ms)):.5f} (std {ms.std(ddof=1):.5f}) rays {np.mean(rays):.4g}", flush=True)
+        print(f"  {label:9s} {tr.last_stats.kernel.decode():34s} mean {ms.mean():.6f} +- {ms.std(ddof=1) / np.sqrt(len(ms)):.6f}  rays {np.mean(rays):.5g}", flush=True)
     world.close()

@@ -144,3 +144,16 @@ def test_cpp_route_with_the_bvh_flag(tmp_path):
     world.close()
     assert np.array_equal(img_bvh, img_py) and info_bvh["rays"] == tracer.last_stats.rays
     assert np.array_equal(img_bvh, img_lin) and info_bvh["rays"] == info_lin["rays"]
+
+
+@needs_bin
+@pytest.mark.gpu
+def test_cpp_route_resident_world_and_repeat(tmp_path):
+    """--repeat renders the frame again on the World that is already in HBM (GpuImageTracer re-uploads only when the
+    flattened World changes): same pixels, and the binary reports the end-to-end time of a resident frame."""
+    args = ("--mode", "path", "--width", 96, "--height", 64, "--aa", 2, "--n_rays", 4, "--roulette", 2, "--max-depth", 4, "--seq", 9)
+    once, info1 = run_gpu_bin(tmp_path, SCENE_TEXT, *args)
+    again, info2 = run_gpu_bin(tmp_path, SCENE_TEXT, *args, "--repeat", 3, "--one-gpu")
+    assert np.array_equal(once, again) and info1["rays"] == info2["rays"]
+    assert 0 < info2["resident_frame_ms"] < 1e3 * info2["elapsed_s"]
+    assert info2["kernel"].startswith("k_render_path_wave") and info2["gpus"] == 1

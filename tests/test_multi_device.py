@@ -104,7 +104,9 @@ def test_frame_host_slices_and_progress(scenes):
         seen = []
         got = tr.fire_all_rays_host(world, mode, n_slices=8, progress=seen.append)
         assert np.array_equal(got, want)
-        assert len(seen) == 8 and seen == sorted(seen) and seen[-1] == 1.0 and seen[0] > 0
+        # deterministic modes: one report per slice; path mode: one launch, up to 8 reports read off its sample queue
+        assert (len(seen) == 8 if mode.mode != "path" else 1 <= len(seen) <= 8)
+        assert seen == sorted(set(seen)) and seen[-1] == 1.0 and seen[0] > 0
         assert int(tr.last_stats.rays) == rays and tr.last_stats.kernel_ms > 0
         assert np.array_equal(tr.fire_all_rays_host(world, mode), want)  # no callback: one launch
         assert int(tr.last_stats.rays) == rays
