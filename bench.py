@@ -37,13 +37,15 @@ sys.path.insert(0, ROOT)
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md)
 
 # fp32 flops one object test costs (FMA = 2, everything else 1), by the arithmetic form a kernel uses:
-#   world-space sphere (wide ISO register rows): oc = O - C (3), b = oc.D (5), c = oc.oc - r^2 (6), disc = b^2 - a c (3)
+#   world-space sphere filter (wide ISO register rows, rt_wide.h): b = O.u - C.u (3 fma = 6), c = (O.O + k) - 2 O.C (1 add + 3 fma = 7),
+#     disc = b^2 - c (1 fma = 2): 15 flops in 8 instructions
 #   object-space sphere, FMA form (sphere_scan_test<true>): D' = M D (15), O' = M O + t (18), a (5), b (5), c (6), disc (3)
 #   object-space sphere as the reference writes it (and the exact kernels execute it): 33 + 19
 #   plane, FMA form: z row only (6 + 5) + t (2); as written: 33 + 2
-F_SPHERE_WORLD, F_SPHERE_OBJECT, F_SPHERE_WRITTEN = 17.0, 52.0, 52.0
+F_SPHERE_WORLD, F_SPHERE_OBJECT, F_SPHERE_WRITTEN = 15.0, 52.0, 52.0
 F_PLANE_FMA, F_PLANE_WRITTEN = 13.0, 35.0
 F_EPILOGUE = 54.0 + 75.0  # the winner's hit record + scatter / shading, same in both counts
+F_EXACT_RECORD = 59.0 + 59.0  # large-world kernels: the winner and the sphere the ray leaves, each once more as the reference writes it
 
 
 def scene_census(scene):
@@ -60,7 +62,7 @@ def flops_per_ray(census, kernel: str):
     n_sph, n_pl = census["spheres"], census["planes"]
     algorithmic = F_SPHERE_WRITTEN * n_sph + 7.0 + F_PLANE_WRITTEN * n_pl + F_EPILOGUE
     if "wide<ISO" in kernel:  # register rows in the world-space form; the big (sky) sphere is scanned per lane
-        executed = F_SPHERE_WORLD * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE
+        executed = F_SPHERE_WORLD * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE + F_EXACT_RECORD
     elif "EXACT" in kernel or "simple" in kernel:  # unfused, the reference's operation order
         executed = algorithmic
     else:  # k_render_path<FMA...>, wide<GEN>: object-space FMA form

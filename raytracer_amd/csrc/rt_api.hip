@@ -620,7 +620,10 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
         wide_lane.push_back(spheres[i]);
       } else {
         wide_recs.push_back(spheres[i]);
-        wide_iso.insert(wide_iso.end(), sphere_iso.begin() + 4 * i, sphere_iso.begin() + 4 * i + 4);
+        // the wide kernel's filter form (rt_wide.h): centre and k = C.C - r^2, in binary64 before rounding
+        const double cx = sphere_iso[4 * i], cy = sphere_iso[4 * i + 1], cz = sphere_iso[4 * i + 2], r = d->shape_fwd[12 * static_cast<size_t>(spheres[i].shape)];
+        wide_iso.insert(wide_iso.end(), sphere_iso.begin() + 4 * i, sphere_iso.begin() + 4 * i + 3);
+        wide_iso.push_back(static_cast<float>(cx * cx + cy * cy + cz * cz - r * r));
       }
     }
   }

@@ -28,35 +28,87 @@ namespace rtd {
 // instructions (c ~ 25: LDS ray read, loop, max, branch), so W is kept as small as the register budget
 // allows: W * K >= number of 64-sphere rows, K <= 8 (ISO) / 4 (general) so that the kernel fits 128 VGPRs.
 
-struct alignas(16) WideRay { // LDS image of one queued ray: 3 x 16 bytes
+// LDS image of one queued ray: 3 x 16 bytes; the scan reads the first two.
+//
+// GEN form: the ray as it is.  ISO form: what the world-space FILTER needs.  Since the winner's t and hit record are
+// recomputed in the reference's arithmetic afterwards (world_finish_hit<true, true>) and the sphere a ray leaves is tested
+// apart (self_sphere_exact), the scan only has to FIND the closest sphere, so it may use the cheapest form that ranks
+// candidates correctly: with a unit direction u = D / |D| and everything that depends on the ray alone or on the sphere
+// alone hoisted out,
+//     b = O.u - C.u                 3 fma      (O.u per ray)
+//     c = (O.O + k) - 2 O.C         1 add + 3 fma      (O.O and -2 O per ray, k = C.C - r^2 per sphere)
+//     disc = b^2 - c                1 fma
+// 8 instructions per test instead of 11.  The price is cancellation in c (|O|^2 + |C|^2 against r^2: an absolute error of
+// a few 1e-6, i.e. the silhouette of a sphere of radius 0.05 is fuzzy by ~0.1 % of its radius, sign at random) — harmless
+// to a filter, and the reason this form was NOT usable while the scan's own t placed the next ray's origin.
+template <bool ISO> struct WideRayT;
+template <> struct alignas(16) WideRayT<false> {
   float ox, oy, oz, tmin;
   float dx, dy, dz, tmax;
   float a, inv_a;             // D.D and its reciprocal
   int self;                   // position in the register rows of the sphere the ray leaves (-1: none): left to self_sphere_exact
   float pad1;
+  RT_DEV static WideRayT make(const Ray &ray, int self) {
+    WideRayT r;
+    r.ox = ray.o.x, r.oy = ray.o.y, r.oz = ray.o.z, r.tmin = ray.tmin;
+    r.dx = ray.d.x, r.dy = ray.d.y, r.dz = ray.d.z, r.tmax = ray.tmax;
+    r.a = fmaf(r.dx, r.dx, fmaf(r.dy, r.dy, r.dz * r.dz));
+    r.inv_a = 1.f / r.a;
+    r.self = self;
+    r.pad1 = 0.f;
+    return r;
+  }
+};
+template <> struct alignas(16) WideRayT<true> {
+  float ux, uy, uz, ou;       // unit direction, O.u
+  float m2ox, m2oy, m2oz, oo; // -2 O, O.O
+  float tmin_u, inv_len;      // tmin as a distance; 1 / |D| (ray parameter = distance / |D|).  tmax is infinite for every ray of the path kernels.
+  int self;
+  float pad1;
+  RT_DEV static WideRayT make(const Ray &ray, int self) {
+    WideRayT r;
+    const float a = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
+    r.inv_len = __builtin_amdgcn_rsqf(a);
+    r.ux = ray.d.x * r.inv_len, r.uy = ray.d.y * r.inv_len, r.uz = ray.d.z * r.inv_len;
+    r.ou = fmaf(ray.o.x, r.ux, fmaf(ray.o.y, r.uy, ray.o.z * r.uz));
+    r.m2ox = -2.f * ray.o.x, r.m2oy = -2.f * ray.o.y, r.m2oz = -2.f * ray.o.z;
+    r.oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    r.tmin_u = ray.tmin * a * r.inv_len; // tmin * |D|
+    r.self = self;
+    r.pad1 = 0.f;
+    return r;
+  }
 };
 
 template <bool ISO, int K> struct WideSlots;
 template <int K> struct WideSlots<true, K> {
-  float cx[K], cy[K], cz[K], r2[K];
+  float cx[K], cy[K], cz[K], kk[K]; // centre, C.C - r^2
   RT_DEV void load(const Scene &s, int k, int sphere, bool valid) {
     if (valid) {
       const float4 v = reinterpret_cast<const float4 *>(s.wide_iso)[sphere];
-      cx[k] = v.x, cy[k] = v.y, cz[k] = v.z, r2[k] = v.w;
-    } else { // empty slot: r^2 = -inf makes c = +inf and disc = -inf (NaN for a zero direction): never > 0, whatever the ray
+      cx[k] = v.x, cy[k] = v.y, cz[k] = v.z, kk[k] = v.w;
+    } else { // empty slot: k = +inf makes c = +inf and disc = -inf: never > 0, whatever the ray
       cx[k] = cy[k] = cz[k] = 0.f;
-      r2[k] = -INF_F;
+      kk[k] = INF_F;
     }
   }
-  RT_DEV float disc(int k, const WideRay &r, float &b) const {
-    const float ocx = r.ox - cx[k], ocy = r.oy - cy[k], ocz = r.oz - cz[k];
-    b = fmaf(ocx, r.dx, fmaf(ocy, r.dy, ocz * r.dz));
-    const float c = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -r2[k])));
-    return fmaf(b, b, -(r.a * c));
+  RT_DEV float disc(int k, const WideRayT<true> &r, float &b) const {
+    b = fmaf(-cx[k], r.ux, fmaf(-cy[k], r.uy, fmaf(-cz[k], r.uz, r.ou)));
+    const float c = fmaf(cx[k], r.m2ox, fmaf(cy[k], r.m2oy, fmaf(cz[k], r.m2oz, r.oo + kk[k])));
+    return fmaf(b, b, -c);
   }
-  RT_DEV float a_of(int, const WideRay &r, float &inv_a) const {
-    inv_a = r.inv_a;
-    return r.a;
+  // front root as a ray parameter (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+  RT_DEV bool front_t(int k, const WideRayT<true> &r, float b, float disc, float &t) const {
+    const float sq = __builtin_amdgcn_sqrtf(disc);
+    const float u1 = -b - sq, u2 = -b + sq;
+    float u = u1;
+    bool ok = true;
+    if (u1 < r.tmin_u) {
+      u = u2;
+      ok = u2 > r.tmin_u;
+    }
+    t = u * r.inv_len;
+    return ok;
   }
 };
 template <int K> struct WideSlots<false, K> {
@@ -76,7 +128,7 @@ template <int K> struct WideSlots<false, K> {
       m[k][9] = 2.f;
     }
   }
-  RT_DEV float disc(int k, const WideRay &r, float &b) {
+  RT_DEV float disc(int k, const WideRayT<false> &r, float &b) {
     const float *q = m[k];
     const float dx = fmaf(q[0], r.dx, fmaf(q[1], r.dy, q[2] * r.dz));
     const float dy = fmaf(q[3], r.dx, fmaf(q[4], r.dy, q[5] * r.dz));
@@ -90,16 +142,23 @@ template <int K> struct WideSlots<false, K> {
     a_[k] = a;
     return fmaf(b, b, -(a * c));
   }
-  RT_DEV float a_of(int k, const WideRay &, float &inv_a) const {
-    inv_a = 1.f / a_[k];
-    return a_[k];
+  RT_DEV bool front_t(int k, const WideRayT<false> &r, float b, float disc, float &t) const {
+    const float sq = __builtin_amdgcn_sqrtf(disc), inv_a = __builtin_amdgcn_rcpf(a_[k]);
+    const float t1 = (-b - sq) * inv_a, t2 = (-b + sq) * inv_a;
+    t = t1;
+    bool ok = true;
+    if (t1 < r.tmin) {
+      t = t2;
+      ok = t2 > r.tmin && t2 < r.tmax;
+    }
+    return ok;
   }
 };
 
 // One queued ray against a lane's K spheres.  The K discriminants are one straight-line block (no branch
 // per sphere); the rare hit work sits behind a single wave-level branch.  A hit merges into the ray's key.
 template <bool ISO, int K, int W>
-RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRay &r, unsigned long long *key_slot, int first, int wave, int lane) {
+RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRayT<ISO> &r, unsigned long long *key_slot, int first, int wave, int lane) {
   float disc[K], b[K];
 #pragma unroll
   for (int k = 0; k < K; ++k)
@@ -115,18 +174,8 @@ RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRay &r, unsigned l
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (disc[k] > 0.f && self_rel != k * W * 64) {
-        float inv_a;
-        slots.a_of(k, r, inv_a);
-        const float sq = sqrtf(disc[k]);
-        const float t1 = (-b[k] - sq) * inv_a;
-        const float t2 = (-b[k] + sq) * inv_a;
-        float t = t1;
-        bool ok = true;
-        if (t1 < r.tmin) {
-          t = t2;
-          ok = t2 > r.tmin && t2 < r.tmax;
-        }
-        if (ok && t < best_t) { // ascending k = ascending object index within a lane
+        float t;
+        if (slots.front_t(k, r, b[k], disc[k], t) && t < best_t) { // ascending k = ascending object index within a lane
           best_t = t;
           best_k = k;
         }
@@ -146,7 +195,7 @@ template <bool ISO, int K, int W>
 __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderParams p) {
   constexpr int WIDE_WAVES = W;
   constexpr int WIDE_THREADS = 64 * W;
-  __shared__ WideRay q_ray[WIDE_THREADS];
+  __shared__ WideRayT<ISO> q_ray[WIDE_THREADS];
   __shared__ unsigned long long q_key[WIDE_THREADS];
   __shared__ int q_count;
   __shared__ PathShared<WIDE_THREADS> sh;
@@ -183,16 +232,11 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
         base = atomicAdd(&q_count, __popcll(live));
       base = __shfl(base, __ffsll((long long)live) - 1, 64);
       my_q = base + rank;
-      WideRay r;
-      r.ox = L.ray.o.x, r.oy = L.ray.o.y, r.oz = L.ray.o.z, r.tmin = L.ray.tmin;
-      r.dx = L.ray.d.x, r.dy = L.ray.d.y, r.dz = L.ray.d.z, r.tmax = L.ray.tmax;
-      r.a = fmaf(r.dx, r.dx, fmaf(r.dy, r.dy, r.dz * r.dz));
-      r.inv_a = 1.f / r.a;
-      r.self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
+      int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
 #ifdef RT_NO_SELF_EXACT
-      r.self = -1;
+      self = -1;
 #endif
-      r.pad1 = 0.f;
+      const WideRayT<ISO> r = WideRayT<ISO>::make(L.ray, self);
       q_ray[my_q] = r;
       q_key[my_q] = ~0ull;
     }
@@ -208,13 +252,13 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
 #pragma unroll
       for (int k = 0; k < K; ++k)
         slots.load(s, k, first + (k * WIDE_WAVES + wave) * 64 + lane, first + (k * WIDE_WAVES + wave) * 64 + lane < s.n_wide);
-      auto test_ray = [&](const WideRay &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
+      auto test_ray = [&](const WideRayT<ISO> &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
       // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
       // the lanes test the current one.
-      WideRay ra = q_ray[0];
+      WideRayT<ISO> ra = q_ray[0];
       int qi = 0;
       for (; qi + 1 < n_q; qi += 2) {
-        const WideRay rb = q_ray[qi + 1];
+        const WideRayT<ISO> rb = q_ray[qi + 1];
         test_ray(ra, qi);
         ra = q_ray[min(qi + 2, n_q - 1)];
         test_ray(rb, qi + 1);

@@ -271,9 +271,10 @@ def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
         diff = np.abs(got - want).max(axis=-1)
         outliers = diff > 1e-4
         print(f"{kind} n={n} {name}: {int(outliers.sum())} of {outliers.size} pixels differ by > 1e-4 (max {diff.max():.3g})")
-        # the unfused kernel follows the oracle's paths except for libm-ulp effects; the FMA kernels leave them where a
-        # hit decision flips, the more often the more spheres a path meets (n=600: 2 %, 1100: 6 %, 4000: 17 %)
-        limit = 0.03 if name == "exact" else (0.10 if n < 2000 else 0.25)
+        # the unfused kernel follows the oracle's paths except for libm-ulp effects; the FMA kernels also leave them where
+        # the filter ranks two near-equal candidates the other way or a scattered direction moves by an ulp (measured:
+        # n=600 0.9 %, 1100 1.8 %, 4000 2.4 %; before the winner's record was recomputed in the reference's arithmetic: 2 / 6 / 17 %)
+        limit = 0.03 if name == "exact" else (0.04 if n < 2000 else 0.06)
         assert outliers.mean() <= limit
         # diverged pixels are other samples of the same estimator: the 960-pixel mean moves by ~sqrt(#diverged) * 0.3 / 960
         assert abs(float(got.mean()) - float(want.mean())) <= (0.01 if n < 2000 else 0.03) * float(want.mean())
