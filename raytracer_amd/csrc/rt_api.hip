@@ -880,7 +880,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
                                         : reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 5>));
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s>", exact ? "EXACT" : "FMA");
       block = rtd::WAVEPATH_THREADS;
-      dyn_lds = rtd::wave_lds_layout(tab[0], tab[1], tab[2], tab[3], tab[4], tab[5], tab[6], sc->dev.n_csg_tops).total;
+      dyn_lds = rtd::wave_lds_layout(L::SHAPES, L::MATERIALS, L::PIGMENTS, L::CSG_LEAVES, L::CSG_PATH, L::CSG_NODES, L::CSG_PROG, L::CSG_TOPS).total;
       nodes_per_level = 64, stacks_per_block = rtd::WAVEPATH_WAVES, node_words = rtd::WAVE_NODE_WORDS;
     } else {
       path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);

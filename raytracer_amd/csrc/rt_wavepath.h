@@ -293,8 +293,7 @@ template <bool FAST> struct WavePath {
 };
 
 // ---------------------------------------------------------------------------------------------
-// The kernel: 4 waves per workgroup share the lookup tables (dynamic LDS, sized by the host from the real table sizes),
-// each wave runs its own pool.
+// The kernel: 4 waves per workgroup share the lookup tables (dynamic LDS), each wave runs its own pool.
 // ---------------------------------------------------------------------------------------------
 constexpr int WAVEPATH_THREADS = 256, WAVEPATH_WAVES = WAVEPATH_THREADS / 64;
 
@@ -302,7 +301,7 @@ struct WaveLdsLayout { // byte offsets into the dynamic LDS block; the same func
   uint32_t w2l, l2w, shade, kind, mat_brdf_pig, mat_emit_pig, mat_needs_uv, pig_kind, pig_c1, pig_c2, pig_n, csg_leaf, csg_leaf_tt, csg_path,
       csg_range, csg_op, csg_prog, csg_tops, total;
 };
-__host__ __device__ inline WaveLdsLayout wave_lds_layout(int n_shapes, int n_materials, int n_pigments, int n_leaves, int n_path, int n_nodes,
+__host__ __device__ constexpr WaveLdsLayout wave_lds_layout(int n_shapes, int n_materials, int n_pigments, int n_leaves, int n_path, int n_nodes,
                                                          int n_prog, int n_tops) {
   WaveLdsLayout L{};
   uint32_t off = WAVEPATH_WAVES * (uint32_t)sizeof(WaveShared);
@@ -331,8 +330,11 @@ template <typename T> RT_DEV void stage_table_at(const T *&table, unsigned char 
 template <bool FAST, int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_path_wave(Scene s, RenderParams p) {
   extern __shared__ __align__(16) unsigned char wave_lds[];
-  const WaveLdsLayout L = wave_lds_layout(p.tab_shapes, p.tab_materials, p.tab_pigments, p.tab_csg_leaves, p.tab_csg_path, p.tab_csg_nodes,
-                                          p.tab_csg_prog, s.n_csg_tops);
+  // the layout is laid out for the LIMITS, not for this scene's table sizes: the offsets are then compile-time constants
+  // (immediate offsets of the ds_read instructions instead of ~20 scalar registers of addresses; measured 2-3 %), and
+  // 31 KB per workgroup still lets 5 workgroups share a CU — all the register budget allows anyway
+  using LIM = PathLdsLimits;
+  constexpr WaveLdsLayout L = wave_lds_layout(LIM::SHAPES, LIM::MATERIALS, LIM::PIGMENTS, LIM::CSG_LEAVES, LIM::CSG_PATH, LIM::CSG_NODES, LIM::CSG_PROG, LIM::CSG_TOPS);
   {
     const int ns = p.tab_shapes, nm = p.tab_materials, np = p.tab_pigments;
     stage_table_at(s.shape_w2l, wave_lds, L.w2l, 12 * ns);

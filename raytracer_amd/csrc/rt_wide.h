@@ -255,6 +255,23 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       auto test_ray = [&](const WideRayT<ISO> &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
       // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
       // the lanes test the current one.
+#ifdef RT_WIDE_PREFETCH3
+      // three register sets: the LDS broadcasts of the next TWO rays are in flight while the lanes test the current one
+      WideRayT<ISO> ra = q_ray[0], rb = q_ray[min(1, n_q - 1)];
+      int qi = 0;
+      for (; qi + 2 < n_q; qi += 3) {
+        const WideRayT<ISO> rc = q_ray[qi + 2];
+        test_ray(ra, qi);
+        ra = q_ray[min(qi + 3, n_q - 1)];
+        test_ray(rb, qi + 1);
+        rb = q_ray[min(qi + 4, n_q - 1)];
+        test_ray(rc, qi + 2);
+      }
+      if (qi < n_q)
+        test_ray(ra, qi);
+      if (qi + 1 < n_q)
+        test_ray(rb, qi + 1);
+#else
       WideRayT<ISO> ra = q_ray[0];
       int qi = 0;
       for (; qi + 1 < n_q; qi += 2) {
@@ -265,6 +282,7 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       }
       if (qi < n_q)
         test_ray(ra, qi);
+#endif
     }
     __syncthreads();
     RT_STAMP(ts2);
