@@ -191,8 +191,16 @@ RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRayT<ISO> &r, unsi
 
 // Register budget: ISO rows cost 4 VGPRs, general rows 13.  Where the rows leave room, ask for 4 waves per
 // SIMD (<= 128 VGPRs), so that several workgroups share a CU and one's shading overlaps another's scan.
+// Waves per SIMD the register budget is set for.  Measured (N=512, W=1): 3 -> 5.98, 4 -> 7.11, 5 -> 7.43 Grays/s; (N=4096, W=8: two
+// 8-wave workgroups per CU whatever the budget, so fewer registers only add spills): 3 -> 0.67, 4 -> 0.98, 5 -> 0.65.
+#ifndef RT_WIDE_OCC
+#define RT_WIDE_OCC (W == 1 ? RT_WIDE_OCC_W1 : 4)
+#endif
+#ifndef RT_WIDE_OCC_W1
+#define RT_WIDE_OCC_W1 5
+#endif
 template <bool ISO, int K, int W>
-__global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderParams p) {
+__global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene s, RenderParams p) {
   constexpr int WIDE_WAVES = W;
   constexpr int WIDE_THREADS = 64 * W;
   __shared__ WideRayT<ISO> q_ray[WIDE_THREADS];
@@ -255,23 +263,8 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       auto test_ray = [&](const WideRayT<ISO> &r, int qi) { wide_test_ray<ISO, K, WIDE_WAVES>(slots, r, q_key + qi, first, wave, lane); };
       // Rays ping-pong between two register sets: the LDS broadcast of the next ray is in flight while
       // the lanes test the current one.
-#ifdef RT_WIDE_PREFETCH3
-      // three register sets: the LDS broadcasts of the next TWO rays are in flight while the lanes test the current one
-      WideRayT<ISO> ra = q_ray[0], rb = q_ray[min(1, n_q - 1)];
-      int qi = 0;
-      for (; qi + 2 < n_q; qi += 3) {
-        const WideRayT<ISO> rc = q_ray[qi + 2];
-        test_ray(ra, qi);
-        ra = q_ray[min(qi + 3, n_q - 1)];
-        test_ray(rb, qi + 1);
-        rb = q_ray[min(qi + 4, n_q - 1)];
-        test_ray(rc, qi + 2);
-      }
-      if (qi < n_q)
-        test_ray(ra, qi);
-      if (qi + 1 < n_q)
-        test_ray(rb, qi + 1);
-#else
+      // (a third register set, two rays in flight, was measured and lost: N=512 7.11 -> 6.71 Grays/s — the registers cost more
+      // in spills than the deeper prefetch hides)
       WideRayT<ISO> ra = q_ray[0];
       int qi = 0;
       for (; qi + 1 < n_q; qi += 2) {
@@ -282,7 +275,6 @@ __global__ void __launch_bounds__(64 * W, 4) k_render_path_wide(Scene s, RenderP
       }
       if (qi < n_q)
         test_ray(ra, qi);
-#endif
     }
     __syncthreads();
     RT_STAMP(ts2);
