@@ -64,7 +64,7 @@ template <> struct alignas(16) WideRayT<true> {
   float m2ox, m2oy, m2oz, oo; // -2 O, O.O
   float tmin_u, inv_len;      // tmin as a distance; 1 / |D| (ray parameter = distance / |D|).  tmax is infinite for every ray of the path kernels.
   int self;
-  float pad1;
+  float tmin;                 // the ray's own tmin (not read by the scan: the lane takes its ray back from here afterwards)
   RT_DEV static WideRayT make(const Ray &ray, int self) {
     WideRayT r;
     const float a = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
@@ -75,8 +75,13 @@ template <> struct alignas(16) WideRayT<true> {
     r.oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
     r.tmin_u = ray.tmin * a * r.inv_len; // tmin * |D|
     r.self = self;
-    r.pad1 = 0.f;
+    r.tmin = ray.tmin;
     return r;
+  }
+  // The ray's origin and tmin, bit for bit (x -> -2x -> -0.5 * that is exact): the lane does not carry them across the scan.
+  RT_DEV void restore(Ray &ray) const {
+    ray.o = mk3(-0.5f * m2ox, -0.5f * m2oy, -0.5f * m2oz);
+    ray.tmin = tmin;
   }
 };
 
@@ -97,8 +102,13 @@ template <int K> struct WideSlots<true, K> {
     const float c = fmaf(cx[k], r.m2ox, fmaf(cy[k], r.m2oy, fmaf(cz[k], r.m2oz, r.oo + kk[k])));
     return fmaf(b, b, -c);
   }
-  // front root as a ray parameter (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
-  RT_DEV bool front_t(int k, const WideRayT<true> &r, float b, float disc, float &t) const {
+  // front root as a ray parameter (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin).  b is
+  // recomputed (3 fma) rather than kept from the discriminant block: K registers less across the block, which is what
+  // lets the one-wave kernel fit 5 waves per SIMD without spilling inside the scan loop.
+  RT_DEV bool front_t(int k, const WideRayT<true> &r, float, float disc, float &t) const {
+    float ou = r.ou;
+    asm volatile("" : "+v"(ou)); // a fresh value: keeps the compiler from carrying the block's b[k] here instead
+    const float b = fmaf(-cx[k], r.ux, fmaf(-cy[k], r.uy, fmaf(-cz[k], r.uz, ou)));
     const float sq = __builtin_amdgcn_sqrtf(disc);
     const float u1 = -b - sq, u2 = -b + sq;
     float u = u1;
@@ -191,6 +201,12 @@ RT_DEV void wide_test_ray(WideSlots<ISO, K> &slots, const WideRayT<ISO> &r, unsi
 
 // Register budget: ISO rows cost 4 VGPRs, general rows 13.  Where the rows leave room, ask for 4 waves per
 // SIMD (<= 128 VGPRs), so that several workgroups share a CU and one's shading overlaps another's scan.
+// At 5 waves per SIMD (96 VGPRs) the one-wave kernel parks part of its lane state in scratch around the scan (the compiler's
+// choice of what: throughput, random state, slot, depth).  What the scan itself does not need was taken out of its way:
+// b[k] is recomputed in the hit path (-8 registers), origin and tmin come back from the ray's queue record (-4).  Scratch
+// 240 -> 168 bytes per lane, L2<->fabric traffic per N=512 frame 5.7 -> 2.9 TB (0.65 TB/s, 8 % of the HBM rate; 0.5 TB at 4 waves per
+// SIMD, where nothing is parked, but that is 6 % slower), 7.44 -> 7.58 Grays/s.  LDS has no room for the rest: 7680 bytes x 20
+// workgroups per CU is 150 of the 160 KB.
 // Waves per SIMD the register budget is set for.  Measured (N=512, W=1): 3 -> 5.98, 4 -> 7.11, 5 -> 7.43 Grays/s; (N=4096, W=8: two
 // 8-wave workgroups per CU whatever the budget, so fewer registers only add spills): 3 -> 0.67, 4 -> 0.98, 5 -> 0.65.
 #ifndef RT_WIDE_OCC
@@ -284,6 +300,8 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
     h.object = h.shape = -1;
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+    if constexpr (ISO)
+      q_ray[max(my_q, 0)].restore(L.ray); // every lane, so that no lane's old values stay live across the scan
     if (L.active) {
       const unsigned long long key = q_key[my_q];
       Best best;
