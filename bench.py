@@ -34,7 +34,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md)
+# MI355X fp32 peak, vector and matrix alike (v_mfma_f32_32x32x2_f32 runs on the VALU's fp32 lanes): 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+# (MI355X_MICROARCH.md: 157.3 TF spec for both, 155 measured on the MFMA)
+FP32_VALU_PEAK_TFLOPS = 157.3
 
 # fp32 flops one object test costs (FMA = 2, everything else 1), by the arithmetic form a kernel uses:
 #   world-space sphere filter (wide ISO register rows, rt_wide.h): b = O.u - C.u (3 fma = 6), c = (O.O + k) - 2 O.C (1 add + 3 fma = 7),
@@ -42,6 +44,9 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 l
 #   object-space sphere, FMA form (sphere_scan_test<true>): D' = M D (15), O' = M O + t (18), a (5), b (5), c (6), disc (3)
 #   object-space sphere as the reference writes it (and the exact kernels execute it): 33 + 19
 #   plane, FMA form: z row only (6 + 5) + t (2); as written: 33 + 2
+#   the same filter on the matrix cores (rt_tile.h): four v_mfma_f32_32x32x2_f32 per 32 rays x 32 spheres = 4 x 4096 / 1024 = 16 flops per
+#     test (K = 4 for b and for c: the constant terms 1 * O.u and k * 1 are multiply-adds too) + the VALU's d = b^2 - c (2): 18
+F_SPHERE_TILE = 18.0
 F_SPHERE_WORLD, F_SPHERE_OBJECT, F_SPHERE_WRITTEN = 15.0, 52.0, 52.0
 F_PLANE_FMA, F_PLANE_WRITTEN = 13.0, 35.0
 F_EPILOGUE = 54.0 + 75.0  # the winner's hit record + scatter / shading, same in both counts
@@ -61,7 +66,9 @@ def flops_per_ray(census, kernel: str):
     kernel named in rt_stats.kernel issues.  CSG trees are not counted in either: a lower bound where a scene has one."""
     n_sph, n_pl = census["spheres"], census["planes"]
     algorithmic = F_SPHERE_WRITTEN * n_sph + 7.0 + F_PLANE_WRITTEN * n_pl + F_EPILOGUE
-    if "wide<ISO" in kernel:  # register rows in the world-space form; the big (sky) sphere is scanned per lane
+    if "path_tile<" in kernel:  # register tiles on the fp32 MFMA; the big (sky) sphere is scanned per lane
+        executed = F_SPHERE_TILE * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE + F_EXACT_RECORD
+    elif "wide<ISO" in kernel:  # register rows in the world-space form; the big (sky) sphere is scanned per lane
         executed = F_SPHERE_WORLD * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE + F_EXACT_RECORD
     elif "EXACT" in kernel or "simple" in kernel:  # unfused, the reference's operation order
         executed = algorithmic
@@ -77,7 +84,8 @@ def roofline_block(census, kernel, rays, kernel_ms, traffic=None, bvh=False):
                 "note": "BVH mode changes the algorithmic work; see DESIGN.md 4.6 for its step counts"}
     executed, algorithmic = flops_per_ray(census, kernel)
     ach = rays * executed / (kernel_ms * 1e-3) / 1e12
-    return {"bound": "valu", "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
+    # the tile kernel's flops run on the binary32 MFMA, whose dense peak equals the vector fp32 peak (it uses the same lanes)
+    return {"bound": "mfma" if "path_tile<" in kernel else "valu", "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
             "traffic": traffic, "kernel": kernel, "flops_per_ray": executed, "rays_per_launch": rays, "kernel_ms": kernel_ms,
             "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": rays * algorithmic / (kernel_ms * 1e-3) / 1e12,
             "note": "achieved / frac count the flops the kernel issues (FMA = 2); algorithmic_* count the reference's arithmetic "

@@ -400,6 +400,7 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 // separate translation units so that the ~30 kernels compile in parallel).
 const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
+const void *rt_tile_kernel(int waves); // rt_wide_tile.hip: k_render_path_tile<8, W>
 
 namespace {
 } // namespace
@@ -627,6 +628,19 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       }
     }
   }
+  std::vector<float> wide_tiles; // rt_tile.h: the MFMA's A operands
+  const size_t n_wide_tiles = all_iso ? (wide_recs.size() + 31) / 32 : 0;
+  wide_tiles.resize(n_wide_tiles * 192);
+  for (size_t t = 0; t < n_wide_tiles; ++t)
+    for (size_t l = 0; l < 64; ++l) {
+      const size_t k = t * 32 + l % 32;
+      const bool valid = k < wide_recs.size(), upper = l >= 32;
+      const float cx = valid ? wide_iso[4 * k] : 0.f, cy = valid ? wide_iso[4 * k + 1] : 0.f, cz = valid ? wide_iso[4 * k + 2] : 0.f;
+      const float kk = valid ? wide_iso[4 * k + 3] : std::numeric_limits<float>::infinity();
+      wide_tiles[t * 192 + l] = upper ? cy : cx;
+      wide_tiles[t * 192 + 64 + l] = upper ? 1.f : cz;
+      wide_tiles[t * 192 + 128 + l] = upper ? kk : cz;
+    }
   std::vector<int32_t> shape_origin(4 * static_cast<size_t>(d->n_shapes), -1);
   for (uint32_t i = 0; i < d->n_shapes; ++i)
     shape_origin[4 * static_cast<size_t>(i) + 3] = 0;
@@ -703,6 +717,8 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, wide_recs, &S.wide_recs));
   UP(upload(sc, wide_iso, &S.wide_iso));
   UP(upload(sc, wide_lane, &S.wide_lane));
+  UP(upload(sc, wide_tiles, &S.wide_tiles));
+  S.n_wide_tiles = static_cast<int32_t>(n_wide_tiles);
   S.n_wide = static_cast<int32_t>(wide_recs.size());
   S.wide_rows = (S.n_wide + 63) / 64;
   S.n_wide_lane = static_cast<int32_t>(wide_lane.size());
@@ -930,6 +946,22 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       block = 64u * static_cast<unsigned>(waves);
       path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wide<%s,K=%d,W=%d>", iso ? "ISO" : "GEN", k, waves);
+      static const bool no_tile = [] { const char *e = std::getenv("RT_NO_TILE"); return e && *e; }(); // tuning aid: the VALU filter instead of the MFMA one
+      if (iso && !no_tile) {
+        // The filter on the matrix cores (rt_tile.h): 8 tiles of 32 spheres per wave and pass.  Waves per workgroup, measured
+        // (Mrays/s; N=512: W=1 9926, W=2 9647 with S=4; N=1024: 5169 / 5244; N=4096: W=1 1215, 2 1271, 4 1402, 8 1350): 1 up to
+        // 16 tiles, 2 up to 32, 4 beyond — small workgroups wait less at their barriers, until the passes get too many.
+        const int tiles = sc->dev.n_wide_tiles;
+        static const int w_env = [] { const char *e = std::getenv("RT_TILE_W"); return e && *e ? std::atoi(e) : 0; }(); // tuning aid
+        waves = 1;
+        while (waves < 4 && tiles > waves * 16)
+          waves *= 2;
+        if (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8)
+          waves = w_env;
+        block = 64u * static_cast<unsigned>(waves);
+        path_kernel = rt_tile_kernel(waves);
+        std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=8,W=%d>", waves);
+      }
     }
     int per_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel, static_cast<int>(block), dyn_lds));

@@ -1,0 +1,212 @@
+// rt_tile.h — the path kernel for large worlds of translation * uniform-scaling spheres: the closest-hit FILTER on the
+// matrix cores (v_mfma_f32_32x32x2_f32), 32 rays x 32 spheres per tile.
+#pragma once
+#include "rt_wide.h"
+
+namespace rtd {
+
+// ---------------------------------------------------------------------------------------------
+// Same pool, queue and finish as k_render_path_wide (rt_wide.h); what changes is who evaluates the filter
+//     b = O.u - C.u,   c = (O.O + k) - 2 O.C,   disc = b^2 - c          (u = D / |D|, k = C.C - r^2; see WideRayT<true>)
+// b and c are inner products of a per-ray vector with a per-sphere vector, so a block of rays against a block of spheres
+// is a small matrix product, and binary32 in / binary32 accumulate MFMAs compute exactly such fmaf chains at the VALU's
+// full fp32 rate, on a pipe of their own:
+//     b[i][j] = sum_k A_b[i][k] B_b[k][j],   A_b = ( cx  cy  cz  1 ) per sphere i,   B_b = ( -ux  -uy  -uz  O.u ) per ray j
+//     c[i][j] = sum_k A_c[i][k] B_c[k][j],   A_c = ( cx  cy  cz  k ),               B_c = ( -2ox -2oy -2oz  1  )
+// two v_mfma_f32_32x32x2_f32 (K = 2 each) per product, four per 1024 tests = 256 matrix-pipe cycles per SIMD, against
+// 8 VALU instructions per 64 tests = 256+ VALU cycles for the same tests before.  O.O stays out of the product (it is the
+// ray's own constant): the VALU forms d = b^2 - c (16 fma per lane per tile) and asks d > O.O.
+//
+// Operand layout of the instruction (probed on the device, scripts/microbench/mfma_probe.hip): lane l supplies
+// A[i = l % 32][k = l / 32] and B[k = l / 32][j = l % 32]; register r of lane l receives D[i = 8 (r / 4) + 4 (l / 32) + r % 4]
+// [j = l % 32].  With spheres as rows and rays as columns a lane IS a ray (j) for the whole tile: what the hit path needs of
+// the ray (O.O, tmin, 1 / |D|, the sphere it leaves) sits in that lane's registers, the sphere's position follows from r,
+// and a lane merges the closest of its candidates over all the wave's sphere tiles into the ray's LDS key once.
+//
+// Spheres in registers: 3 per lane per 32-sphere tile (a1 = cx | cy for the lower | upper half of the wave, a2 = cz | 1,
+// a3 = cz | k), prepared by the host (Scene::wide_tiles).  S = 8 tiles per wave and pass (256 spheres in 24 registers; bigger
+// worlds take several passes, the registers reloaded from L2 per pass).  Measured, N=512, W=1: S=4 9822, S=8 9926, S=16 8900
+// Mrays/s (at 16 the lane state that shading needs is spilled around the scan); 5 waves per SIMD (96 VGPRs): 8950.
+//
+// What it buys (N=512 1080p AA=4 / the 68-row slice of N=4096): 7.60 -> 9.93 and 1.02 -> 1.40 Grays/s over the VALU filter of
+// rt_wide.h.  The binary32 MFMA and the VALU share the SIMD's fp32 lanes (scripts/microbench/mfma_probe.hip: 4 MFMAs alone
+// take 278 cycles per tile, + 24 VALU instructions 345, + 72 459 — the times add, they do not overlap), so the gain is not a
+// second pipe but instruction efficiency: the 4 MFMAs carry 16 of the 18 flops per test at the full rate of 64 per cycle and
+// SIMD, where the VALU filter issued its 8 instructions per test at 3.9 cycles each instead of 2.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS image of one queued ray: quad 0 is read by lanes 0-31 (k = 0 of every product), quad 1 by lanes 32-63 (k = 1),
+// quad 2 by both.
+struct alignas(16) TileRay {
+  float nux, nuz, m2ox, m2oz;  // -ux, -uz, -2 ox, -2 oz
+  float nuy, ou, m2oy, tmin;   // -uy, O.u, -2 oy; the reader puts 1 in the fourth place, the slot keeps the ray's own tmin
+  float oo, tmin_u, inv_len;   // O.O; tmin as a distance; 1 / |D|
+  int self;                    // position among the register spheres of the sphere the ray leaves (-1: none)
+  RT_DEV static TileRay make(const Ray &ray, int self) {
+    TileRay r;
+    const float a = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
+    r.inv_len = __builtin_amdgcn_rsqf(a);
+    const float ux = ray.d.x * r.inv_len, uy = ray.d.y * r.inv_len, uz = ray.d.z * r.inv_len;
+    r.nux = -ux, r.nuy = -uy, r.nuz = -uz;
+    r.ou = fmaf(ray.o.x, ux, fmaf(ray.o.y, uy, ray.o.z * uz));
+    r.m2ox = -2.f * ray.o.x, r.m2oy = -2.f * ray.o.y, r.m2oz = -2.f * ray.o.z;
+    r.oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    r.tmin_u = ray.tmin * a * r.inv_len;
+    r.tmin = ray.tmin;
+    r.self = self;
+    return r;
+  }
+  // origin and tmin bit for bit (x -> -2x -> -0.5 * that is exact): the lane does not carry them across the scan
+  RT_DEV void restore(Ray &ray) const {
+    ray.o = mk3(-0.5f * m2ox, -0.5f * m2oy, -0.5f * m2oz);
+    ray.tmin = tmin;
+  }
+};
+
+#ifndef RT_TILE_OCC
+#define RT_TILE_OCC 4
+#endif
+template <int S, int W>
+__global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene s, RenderParams p) {
+  constexpr int T = 64 * W;
+  __shared__ TileRay q_ray[T];
+  __shared__ unsigned long long q_key[T];
+  __shared__ int q_count;
+  __shared__ PathShared<T> sh;
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int n_tiles = s.n_wide_tiles;
+  const int n_pass = (n_tiles + S * W - 1) / (S * W);
+  PathBlock<T, true> L;
+  L.init(p, sh);
+
+  for (;;) {
+    // -- every lane gets a ray from the workgroup's node pool; the live rays are queued (compacted) ----
+    if (threadIdx.x == 0)
+      q_count = 0;
+    if (!L.deal(s, p, sh)) // synchronises the workgroup
+      break;
+    int my_q = -1;
+    if (L.active) {
+      const unsigned long long live = __ballot(1);
+      const int rank = __popcll(live & ((1ull << lane) - 1ull));
+      int base = 0;
+      if (rank == 0)
+        base = atomicAdd(&q_count, __popcll(live));
+      base = __shfl(base, __ffsll((long long)live) - 1, 64);
+      my_q = base + rank;
+      const int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
+      q_ray[my_q] = TileRay::make(L.ray, self);
+      q_key[my_q] = ~0ull;
+    }
+    __syncthreads();
+    const int n_q = q_count;
+
+    // -- the filter: every wave takes the queued rays 32 at a time against its sphere tiles -------------
+    for (int pass = 0; pass < n_pass; ++pass) {
+      // tile s_ of this wave in this pass is sphere tile first + s_ * W + wave (positions ascend with the object index)
+      const int first = pass * S * W;
+      const int first_w = first + __builtin_amdgcn_readfirstlane(wave);
+      const int n_s = min(S, max(0, (n_tiles - first_w + W - 1) / W));
+      float a1[S], a2[S], a3[S];
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int tile = min(first + s_ * W + wave, n_tiles - 1); // tiles past n_s are not multiplied
+        const float *rec = s.wide_tiles + (size_t)tile * 192 + lane;
+        a1[s_] = rec[0], a2[s_] = rec[64], a3[s_] = rec[128];
+      }
+      for (int r0 = 0; r0 < n_q; r0 += 32) {
+        const int n = r0 + col;
+        const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[min(n, n_q - 1)]);
+        const float4 qa = rec[half], qc = rec[2];
+        const float bq1 = qa.x, bq2 = qa.y, cq1 = qa.z, cq2 = half ? 1.f : qa.w;
+        const float oo = n < n_q ? qc.x : INF_F; // a lane past the queue's end asks d > +inf
+        const float tmin_u = qc.y, inv_len = qc.z;
+        const int self = __float_as_int(qc.w);
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+          __builtin_amdgcn_sched_barrier(0); // one tile at a time: interleaving the tiles' accumulators spills them
+          if (s_ < n_s) { // uniform over the wave
+            f32x16 b = {0}, c = {0};
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], bq1, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], cq1, c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s_], bq2, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s_], cq2, c, 0, 0, 0);
+            float d[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              d[r] = fmaf(b[r], b[r], -c[r]);
+            // maxima of the four blocks of 4 consecutive spheres this lane has, then of the tile (v_max3_f32 + v_max_f32 each)
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              g[k] = fmaxf(fmaxf(fmaxf(d[4 * k], d[4 * k + 1]), d[4 * k + 2]), d[4 * k + 3]);
+            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
+            if (m > oo) { // this ray's line meets one of the tile's spheres
+              // the tile's first position is wave-uniform; the lane's own part (the lower or upper 4 of each 8 rows) is made
+              // opaque here so that the 256 positions of a pass are not all computed ahead of the loops and kept in registers
+              int h4 = 4 * half;
+              asm volatile("" : "+v"(h4));
+              const int base = (first_w + s_ * W) * 32 + h4; // position of this lane's row 0
+              const int self_rel = self - base;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (g[k] > oo) {
+#pragma unroll
+                  for (int r = 4 * k; r < 4 * k + 4; ++r) {
+                    if (d[r] > oo) {
+                      const int row = 8 * (r >> 2) + (r & 3); // a literal
+                      // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+                      const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
+                      const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                      const float u = u1 < tmin_u ? u2 : u1;
+                      if (u > tmin_u && self_rel != row) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(base + row);
+                        best = min(best, key); // equal t: the lowest position = the lowest object index, the reference's strict `<`
+                      }
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (best != ~0ull)
+          atomicMin(&q_key[n], best);
+      }
+    }
+    __syncthreads();
+
+    // -- every lane is a ray again: finish the query, shade, produce the next ray -------------------
+    Hit h;
+    h.object = h.shape = -1;
+    h.t = 0.f;
+    h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+    q_ray[max(my_q, 0)].restore(L.ray); // every lane, so that no lane's old values stay live across the scan
+    if (L.active) {
+      const unsigned long long key = q_key[my_q];
+      Best best;
+      best.t = INF_F;
+      best.object = 0x7fffffff;
+      best.shape = -1;
+      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best, L.origin_shape); // in object order: strict `<` among them
+      self_sphere_exact(s, L.origin_shape, L.ray, best);
+      if (key != ~0ull) {
+        const int2 ids = *reinterpret_cast<const int2 *>(&s.wide_recs[(int)(unsigned)(key & 0xffffffffull)].object); // {object, shape}
+        const float t = __uint_as_float((unsigned)(key >> 32));
+        if (t < best.t || (t == best.t && ids.x < best.object)) {
+          best.t = t;
+          best.object = ids.x;
+          best.shape = ids.y;
+        }
+      }
+      h = world_finish_hit<true, true>(s, L.ray, best);
+    }
+    L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
+  }
+  wave_add_tally(p.counters, 0, L.rays);
+}
+
+} // namespace rtd

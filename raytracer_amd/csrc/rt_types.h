@@ -79,6 +79,9 @@ struct Scene {
   // ones scanned per lane instead (big spheres, a short leftover), ascending too
   const ScanRec *wide_recs; const float *wide_iso; int32_t n_wide, wide_rows;
   const ScanRec *wide_lane; int32_t n_wide_lane;
+  // the same register spheres as MFMA operands (rt_tile.h): per tile of 32, three rows of 64 floats — lane l of a wave takes
+  // cx | cy, cz | 1, cz | k of sphere l % 32 for l < 32 | l >= 32; a place past n_wide holds 0 0 0 and k = +inf (never hit)
+  const float *wide_tiles; int32_t n_wide_tiles;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   // RT_FLAG_ACCEL_BVH (rt_bvh.h): heap of n_bvh_nodes slots (0: no hierarchy); the spheres inside it regrouped by
   // leaf (records, and centre + r^2 when spheres_all_iso); the spheres too big for it, scanned linearly first

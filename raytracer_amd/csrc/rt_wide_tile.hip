@@ -1,0 +1,16 @@
+// rt_wide_tile.hip — instantiations of k_render_path_tile<S, W> (rt_tile.h).
+#include <hip/hip_runtime.h>
+
+#include "rt_tile.h"
+
+#define RT_T(SS, WW) reinterpret_cast<const void *>(rtd::k_render_path_tile<SS, WW>)
+
+// 8 sphere tiles per wave and pass (measured against 4 and 16, see rt_tile.h), `waves` waves per workgroup
+const void *rt_tile_kernel(int waves) {
+  switch (waves) {
+  case 1: return RT_T(8, 1);
+  case 2: return RT_T(8, 2);
+  case 4: return RT_T(8, 4);
+  default: return RT_T(8, 8);
+  }
+}

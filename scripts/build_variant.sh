@@ -10,13 +10,13 @@ make -s ../libraytracer_amd.so
 out=build/variants/$name
 mkdir -p "$out"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -fvisibility=hidden "$@" -c rt_api.hip -o "$out/rt_api.o"
-wide="build/rt_wide_iso.o build/rt_wide_gen.o"
+wide="build/rt_wide_iso.o build/rt_wide_gen.o build/rt_wide_tile.o"
 if [ -n "$ALL" ]; then
-  for f in rt_wide_iso rt_wide_gen; do
+  for f in rt_wide_iso rt_wide_gen rt_wide_tile; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -fvisibility=hidden "$@" -c $f.hip -o "$out/$f.o" &
   done
   wait
-  wide="$out/rt_wide_iso.o $out/rt_wide_gen.o"
+  wide="$out/rt_wide_iso.o $out/rt_wide_gen.o $out/rt_wide_tile.o"
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/rt_api.o" $wide -o "$out/libraytracer_amd.so"
 echo "$PWD/$out/libraytracer_amd.so"

@@ -50,7 +50,7 @@ def test_gpu_flat_equals_reference(ref_images, big_scenes, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,w,h,kernel", [(512, 128, 72, "k_render_path_wide<ISO,K=8,W=1>"), (4096, 48, 27, "k_render_path_wide<ISO,K=8,W=8>")])
+@pytest.mark.parametrize("n,w,h,kernel", [(512, 128, 72, "k_render_path_tile<S=8,W=1>"), (4096, 48, 27, "k_render_path_tile<S=8,W=4>")])
 def test_gpu_wide_kernel_converges_to_reference_render(ref_images, big_scenes, n, w, h, kernel):
     from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
     scene = big_scenes[n]
