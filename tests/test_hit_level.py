@@ -1,4 +1,4 @@
-"""Hit-level check of the FAST closest-hit scans (the wide register-row kernel in both sphere forms, and the BVH kernel)
+"""Hit-level check of the FAST closest-hit scans (the tile kernel with its MFMA filter, the register-row kernel in the object-space form, and the BVH kernel)
 against the unfused scan and the CPU oracle, ray by ray — not through image statistics.
 
 Trick: path mode with n_rays = 1, max-depth = 1 and no Russian roulette traces exactly two rays per sample, and with

@@ -6,8 +6,8 @@ the 4096-sphere path render alone is 48 minutes of the reference's CPU time).
   * flat renders (every object tested per ray, no randomness): the CPU oracle and the GPU reproduce the reference
     bit for bit, 4098 objects included;
   * path 10/3/5 renders: the reference consumes ONE serial PCG, the device gives every ray its own stream, so the
-    comparison is statistical: the default kernels for these worlds — the fused wide kernel, world-space sphere form,
-    K = 8 register rows, W = 1 wave (N = 512) and W = 8 waves (N = 4096) — rendered with four seeds against the
+    comparison is statistical: the default kernels for these worlds — the tile kernel (sphere filter on the fp32 matrix
+    cores, rt_tile.h), W = 1 wave per workgroup (N = 512) and W = 4 (N = 4096) — rendered with four seeds against the
     reference's single render: image mean within 4 standard errors (measured from the seeds) AND within 1.5 %, and the
     per-pixel difference within the seeds' own spread for > 95 % of the pixels.
 """
