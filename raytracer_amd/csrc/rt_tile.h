@@ -138,12 +138,12 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               d[r] = fmaf(b[r], b[r], -c[r]);
-            // maxima of the four blocks of 4 consecutive spheres this lane has, then of the tile (v_max3_f32 + v_max_f32 each)
-            float g[4];
+            // maxima of five blocks of 3 registers (v_max3_f32 each) and the tile maximum: 8 instructions for the 16 values
+            float g[5];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              g[k] = fmaxf(fmaxf(fmaxf(d[4 * k], d[4 * k + 1]), d[4 * k + 2]), d[4 * k + 3]);
-            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
+            for (int k = 0; k < 5; ++k)
+              g[k] = fmaxf(fmaxf(d[3 * k], d[3 * k + 1]), d[3 * k + 2]);
+            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(fmaxf(g[3], g[4]), d[15]));
             if (m > oo) { // this ray's line meets one of the tile's spheres
               // the tile's first position is wave-uniform; the lane's own part (the lower or upper 4 of each 8 rows) is made
               // opaque here so that the 256 positions of a pass are not all computed ahead of the loops and kept in registers
@@ -151,25 +151,28 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
               asm volatile("" : "+v"(h4));
               const int base = (first_w + s_ * W) * 32 + h4; // position of this lane's row 0
               const int self_rel = self - base;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if (g[k] > oo) {
-#pragma unroll
-                  for (int r = 4 * k; r < 4 * k + 4; ++r) {
-                    if (d[r] > oo) {
-                      const int row = 8 * (r >> 2) + (r & 3); // a literal
-                      // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
-                      const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
-                      const float u1 = -b[r] - sq, u2 = -b[r] + sq;
-                      const float u = u1 < tmin_u ? u2 : u1;
-                      if (u > tmin_u && self_rel != row) {
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(base + row);
-                        best = min(best, key); // equal t: the lowest position = the lowest object index, the reference's strict `<`
-                      }
-                    }
+              auto candidate = [&](int r) {
+                if (d[r] > oo) {
+                  const int row = 8 * (r >> 2) + (r & 3); // a literal
+                  // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+                  const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
+                  const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                  const float u = u1 < tmin_u ? u2 : u1;
+                  if (u > tmin_u && self_rel != row) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(base + row);
+                    best = min(best, key); // equal t: the lowest position = the lowest object index, the reference's strict `<`
                   }
                 }
+              };
+#pragma unroll
+              for (int k = 0; k < 5; ++k) {
+                if (g[k] > oo) {
+                  candidate(3 * k);
+                  candidate(3 * k + 1);
+                  candidate(3 * k + 2);
+                }
               }
+              candidate(15);
             }
           }
         }

@@ -41,6 +41,17 @@ template <int S, int MODE> __global__ void __launch_bounds__(64, 4) k_rate(const
       float m;
       if (MODE == 0) {
         m = b[0] + c[0];
+      } else if (MODE == 6) { // 24 integer instructions on the MFMA results, no fp32 VALU work
+        int x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          x[r] = __float_as_int(b[r]) ^ (__float_as_int(c[r]) >> 1);
+        int mi = max(max(x[0], x[1]), x[2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2)
+          mi = max(max(mi, x[r]), x[r + 1]);
+        mi = max(mi, x[15]);
+        m = __int_as_float(mi);
       } else {
         float d[16];
 #pragma unroll
@@ -53,7 +64,14 @@ template <int S, int MODE> __global__ void __launch_bounds__(64, 4) k_rate(const
             for (int r = 0; r < 16; ++r)
               d[r] = fmaf(d[r], b[r], c[(r + j) & 15]);
         }
-        if (MODE == 1) {
+        if (MODE == 5) { // integer maxima of the same bits
+          int mi = max(max(__float_as_int(d[0]), __float_as_int(d[1])), __float_as_int(d[2]));
+#pragma unroll
+          for (int r = 3; r + 1 < 16; r += 2)
+            mi = max(max(mi, __float_as_int(d[r])), __float_as_int(d[r + 1]));
+          mi = max(mi, __float_as_int(d[15]));
+          m = __int_as_float(mi);
+        } else if (MODE == 1) {
           m = d[0];
 #pragma unroll
           for (int r = 1; r < 16; ++r)
@@ -120,5 +138,7 @@ int main() {
   run<8, 2>(sph, out, 1), run<8, 2>(sph, out, 2), run<8, 2>(sph, out, 4);
   run<8, 3>(sph, out, 1), run<8, 3>(sph, out, 2), run<8, 3>(sph, out, 4);
   run<8, 4>(sph, out, 1), run<8, 4>(sph, out, 2), run<8, 4>(sph, out, 4);
+  run<8, 5>(sph, out, 2), run<8, 5>(sph, out, 4);
+  run<8, 6>(sph, out, 2), run<8, 6>(sph, out, 4);
   return 0;
 }
