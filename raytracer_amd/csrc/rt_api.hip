@@ -107,6 +107,9 @@ struct rt_scene {
   rtd::Scene dev{};              // device pointers
   unsigned long long *counters = nullptr; // rtd::COUNTER_WORDS x u64
   int32_t tab[7] = {0, 0, 0, 0, 0, 0, 0}; // table sizes: shapes, materials, pigments, csg leaves / chain steps / nodes / program entries
+  // what the world-space sphere filter's rounding error depends on (see world_filter_ok): the farthest register sphere from
+  // the origin (|C| + r) and the smallest r^2 among them
+  double wide_reach = 0.0, wide_rmin2 = 0.0;
   DeviceBuffer samples, stack;   // grow-only scratch reused across renders
   DeviceBuffer frame;            // rt_render_frame_host: the frame while it is in HBM
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -628,6 +631,14 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       }
     }
   }
+  double wide_reach = 0.0, wide_rmin2 = std::numeric_limits<double>::infinity();
+  if (all_iso)
+    for (size_t k = 0; k < wide_recs.size(); ++k) {
+      const double cx = wide_iso[4 * k], cy = wide_iso[4 * k + 1], cz = wide_iso[4 * k + 2];
+      const double r = std::fabs(static_cast<double>(d->shape_fwd[12 * static_cast<size_t>(wide_recs[k].shape)]));
+      wide_reach = std::max(wide_reach, std::sqrt(cx * cx + cy * cy + cz * cz) + r);
+      wide_rmin2 = std::min(wide_rmin2, r * r);
+    }
   std::vector<float> wide_tiles; // rt_tile.h: the MFMA's A operands
   const size_t n_wide_tiles = all_iso ? (wide_recs.size() + 31) / 32 : 0;
   wide_tiles.resize(n_wide_tiles * 192);
@@ -719,6 +730,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, wide_lane, &S.wide_lane));
   UP(upload(sc, wide_tiles, &S.wide_tiles));
   S.n_wide_tiles = static_cast<int32_t>(n_wide_tiles);
+  sc->wide_reach = wide_reach, sc->wide_rmin2 = wide_rmin2;
   S.n_wide = static_cast<int32_t>(wide_recs.size());
   S.wide_rows = (S.n_wide + 63) / 64;
   S.n_wide_lane = static_cast<int32_t>(wide_lane.size());
@@ -789,6 +801,26 @@ void rt_scene_destroy(rt_scene *sc) {
 } // extern "C"
 
 namespace {
+
+// The world-space sphere filter (rt_tile.h, rt_wide.h ISO form) computes c = (C.C - r^2) - 2 O.C + O.O in binary32: terms of
+// size |O|^2 + |C|^2 cancel down to something compared with r^2, leaving a rounding error of about 2^-22 (|O|^2 + |C|^2) — a
+// silhouette fuzzy by that much, sign at random.  At the benchmark's scale (coordinates ~10, r >= 0.05) that is 2 % of the
+// smallest r^2 and the frames agree with the reference's own renders (tests/test_synth_large.py); a world far from the origin
+// or with tiny spheres would silently lose accuracy, so such worlds take the object-space kernel (k_render_path_wide<GEN>:
+// the ray is mapped into each sphere's frame first, nothing cancels).  Ray origins are bounded by the camera's and by the
+// spheres' own reach (rays leaving far points of an unbounded plane are not: their share of a frame is negligible).
+bool world_filter_ok(const rt_scene *sc, const rt_camera *cam) {
+  const float *m = cam->fwd;
+  const double col0 = std::sqrt(double(m[0]) * m[0] + double(m[3]) * m[3] + double(m[6]) * m[6]);
+  const double col1 = std::sqrt(double(m[1]) * m[1] + double(m[4]) * m[4] + double(m[7]) * m[7]);
+  const double col2 = std::sqrt(double(m[2]) * m[2] + double(m[5]) * m[5] + double(m[8]) * m[8]);
+  const double shift = std::sqrt(double(m[9]) * m[9] + double(m[10]) * m[10] + double(m[11]) * m[11]);
+  const double asp = cam->has_asp_ratio ? std::fabs(double(cam->asp_ratio)) : 2.0;
+  const double cam_reach = shift + std::max(1.0, std::fabs(double(cam->distance))) * col0 + asp * col1 + col2; // both camera kinds
+  const double o = std::max(cam_reach, sc->wide_reach), c = sc->wide_reach;
+  const double err = std::ldexp(o * o + c * c, -22);
+  return err <= 0.05 * sc->wide_rmin2;
+}
 
 // Where one render keeps what it needs beyond the scene and the framebuffer (tally counters, the sample buffer when
 // spp > 1, the node stacks of path mode): grow-only buffers of the scene handle (rt_render), or a fixed workspace the
@@ -935,7 +967,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
     if (use_wide) {
-      const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES);
+      const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) && world_filter_ok(sc, cam);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.
       const int kmax = iso ? 8 : 4;

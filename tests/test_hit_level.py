@@ -31,24 +31,30 @@ pytestmark = pytest.mark.gpu
 W, H = 192, 108
 
 
-def id_world(n, seed=11):
+def id_world(n, seed=11, shift=(0.0, 0.0, 0.0)):
+    """`shift` moves the whole world and its camera away from the origin (binary32 coordinates throughout)."""
     rng = np.random.default_rng(seed)
+    shift = np.asarray(shift, dtype=np.float64)
+
+    def at(p):
+        return [float(np.float32(x)) for x in np.asarray(p, dtype=np.float64) + shift]
+
     b = SceneBuilder()
     geo = []  # per object: None (not a small sphere) or (centre, radius)
 
     def mat(obj_id, reflect=(0.0, 1.0, 0.0)):
         return b.material("specular", b.pigment_uniform(reflect), b.pigment_uniform((obj_id, obj_id, obj_id)))
 
-    b.plane(compose(translation([0, 0, -2])), mat(1))
+    b.plane(compose(translation(at([0, 0, -2]))), mat(1))
     geo.append(None)
-    b.sphere(compose(scaling([50, 50, 50])), mat(2, (0.0, 0.0, 0.0)))  # the sky reflects nothing: the path ends there
+    b.sphere(compose(translation(at([0, 0, 0])), scaling([50, 50, 50])), mat(2, (0.0, 0.0, 0.0)))  # the sky reflects nothing: the path ends there
     geo.append(None)
     for k in range(n):
         r = float(np.float32(rng.uniform(0.05, 0.15)))
-        c = [float(np.float32(x)) for x in rng.uniform([-2, -6, -2 + r], [8, 6, 2])]
+        c = at([float(np.float32(x)) for x in rng.uniform([-2, -6, -2 + r], [8, 6, 2])])
         b.sphere(compose(translation(c), scaling([r, r, r])), mat(3 + k))
         geo.append((np.array(c, dtype=np.float64), r))
-    b.set_camera("perspective", compose(translation([-3, 0, 0])), None, 1.0)
+    b.set_camera("perspective", compose(translation(at([-3, 0, 0]))), None, 1.0)
     return b.build(), geo
 
 
@@ -129,3 +135,23 @@ def test_fast_scans_pick_the_reference_winner(n):
         self_hit = second & ((got2 == got1) | (ref2 == ref1))
         print(f"  of the second-hit differences {int(self_hit.sum())} are own-sphere re-hits on one side")
         assert (second & ~self_hit).mean() <= 0.005 and self_hit.mean() <= 0.01
+
+
+def test_world_far_from_the_origin_takes_the_object_space_kernel():
+    """The world-space filter's rounding error grows with |O|^2 + |C|^2 (rt_api.hip world_filter_ok): a world 400 units from
+    the origin with spheres of radius 0.05-0.15 must not use it.  The object-space kernel it takes instead names the unfused
+    kernel's winners (which IS the oracle, see above) on all but a few silhouette pixels, at this distance too."""
+    scene, _ = id_world(600, shift=(300.0, -250.0, 60.0))
+    kw = dict(n_rays=1, roulette=5, max_depth=1, seq_number=3)
+    world = DeviceWorld(scene)
+    tr = GpuImageTracer(W, H, scene.camera, 1)
+    ref1, ref2 = ids_of(tr.fire_all_rays(world, RenderMode("path", exact=True, **kw)))
+    got1, got2 = ids_of(tr.fire_all_rays(world, RenderMode("path", **kw)))
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_wide<GEN")
+    world.close()
+    want = ids_of(O.render(scene, O.make_cfg(W, H, "path", spp_edge=1, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))[0])
+    assert np.array_equal(ref1, want[0]) and np.array_equal(ref2, want[1])
+    assert len(np.unique(ref1)) > 100
+    print(f"far world: {int((got1 != ref1).sum())} first-hit ids differ, {int(((got2 != ref2) & (got1 == ref1)).sum())} second-hit ids differ, of {W * H}")
+    assert (got1 != ref1).mean() <= 0.005
+    assert ((got2 != ref2) & (got1 == ref1)).mean() <= 0.02
