@@ -76,3 +76,43 @@ def test_gpu_wide_kernel_converges_to_reference_render(ref_images, big_scenes, n
     assert np.mean(z < 4.0) > 0.95
     # the optional BVH mode on the same world: another seed of the same estimator
     assert abs(bvh.astype(np.float64).mean() - ref.mean()) <= 5 * means.std(ddof=1) * np.sqrt(2) + 0.015 * ref.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 4096])
+def test_furnace_identity_at_full_sphere_counts(n):
+    """A size-independent property at the headline worlds' sizes (the reference's own furnace test, test/renderers_test.cpp,
+    uses one sphere): when every surface of a closed world emits Le and reflects rho diffusely, the radiance seen along any
+    ray is Le (1 + rho + ... + rho^max_depth) whatever the geometry.  With Le = 1, rho = 1/2 and n_rays = 2 every weight is
+    a power of two and the sums are 64-bit fixed point, so a pixel equals 1.9375 EXACTLY unless one of its rays leaks — through
+    the tile kernel (W = 1 and W = 4), the object-space kernel and the BVH kernel, N small spheres + floor inside the sky
+    sphere.  Leaks exist in the reference's own arithmetic (the CPU oracle, which reproduces the reference bit for bit, loses
+    one ray of 642 816 on the N = 512 world: a scattered ray that starts a rounding error away from two touching surfaces), so
+    the bar is: never above, at most 1 pixel in 1000 below, and those by less than 2 %."""
+    from raytracer_amd.scene import SceneBuilder, compose, scaling, translation
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    rng = np.random.default_rng(n)
+    b = SceneBuilder()
+    m = b.material("diffuse", b.pigment_uniform((0.5, 0.5, 0.5)), b.pigment_uniform((1.0, 1.0, 1.0)))
+    b.plane(compose(translation([0, 0, -2])), m)
+    b.sphere(compose(scaling([50, 50, 50])), m)
+    for _ in range(n):
+        r = float(np.float32(rng.uniform(0.05, 0.15)))
+        c = [float(np.float32(x)) for x in rng.uniform([-2, -6, -2 + r], [8, 6, 2])]
+        b.sphere(compose(translation(c), scaling([r, r, r])), m)
+    b.set_camera("perspective", compose(translation([-3, 0, 0])), None, 1.0)
+    scene = b.build()
+    world = DeviceWorld(scene)
+    tr = GpuImageTracer(96, 54, scene.camera, 2)
+    kw = dict(n_rays=2, roulette=99, max_depth=4, seq_number=7)
+    for name, mode in (("tile", RenderMode("path", **kw)), ("object-space", RenderMode("path", object_space_spheres=True, **kw)),
+                       ("bvh", RenderMode("path", bvh=True, **kw))):
+        img = tr.fire_all_rays(world, mode)
+        if name == "tile":
+            assert tr.last_stats.kernel.decode() == f"k_render_path_tile<S=8,W={1 if n == 512 else 4}>"
+        full = 96 * 54 * 4 * 31  # every ray hits something: full binary trees of depth 4
+        assert full * (1 - 1e-4) <= int(tr.last_stats.rays) <= full
+        print(f"n={n} {name}: {full - int(tr.last_stats.rays)} rays short of {full}, {int((img != np.float32(1.9375)).any(axis=2).sum())} pixels off, min {img.min()}")
+        assert img.max() == np.float32(1.9375) and img.min() >= 1.9375 * 0.98
+        assert (img != np.float32(1.9375)).any(axis=2).mean() <= 1e-3
+    world.close()
