@@ -404,6 +404,9 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
 const void *rt_tile_kernel(int waves); // rt_wide_tile.hip: k_render_path_tile<8, W>
+#ifndef RT_WAVE_OCC_NO_CSG
+#define RT_WAVE_OCC_NO_CSG 6
+#endif
 
 namespace {
 } // namespace
@@ -919,16 +922,24 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const bool use_wave = small_tables && !use_bvh && !use_wide;
     int nodes_per_level = 0, stacks_per_block = 1, node_words = rtd::NODE_WORDS; // nodes_per_level 0: the block size, set below
     if (use_wave) {
-      // waves per SIMD: 4 (128 VGPRs, no spills) is best without CSG objects, 5 (96 VGPRs) with them — measured on C3 / C4
+      // Worlds without CSG objects run the variant compiled without the evaluators and their tables (102 VGPRs at 4 waves per
+      // SIMD, 94 at 5, 80 at 6 with 2 spilled; 25 KB of LDS, so 6 workgroups fit a CU): measured on C3, waves per SIMD
+      // 4 -> 15.0, 5 -> 14.1, 6 -> 13.8 ms (the kernel with the CSG code: 15.6 at 4, its best).
+      // With CSG objects: 5 (96 VGPRs) beats 4 and 6 — measured on C4: 46.1 / 43.7 / 62.7 ms.
       static const int occ_env = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 0; }(); // tuning aid
-      const int occ = occ_env ? occ_env : (sc->dev.n_csg_tops > 0 ? 5 : 4);
-      path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path_wave<false, 4>)
-                          : (occ == 4   ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 4>)
-                             : occ == 6 ? reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 6>)
-                                        : reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 5>));
-      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s>", exact ? "EXACT" : "FMA");
+      const bool csg = sc->dev.n_csg_tops > 0;
+      const int occ = occ_env ? occ_env : (csg ? 5 : RT_WAVE_OCC_NO_CSG);
+#define RT_WAVE_K(FAST, OCC, CSG) reinterpret_cast<const void *>(rtd::k_render_path_wave<FAST, OCC, CSG>)
+      if (exact)
+        path_kernel = RT_WAVE_K(false, 4, true);
+      else if (csg)
+        path_kernel = occ == 4 ? RT_WAVE_K(true, 4, true) : occ == 6 ? RT_WAVE_K(true, 6, true) : RT_WAVE_K(true, 5, true);
+      else
+        path_kernel = occ == 4 ? RT_WAVE_K(true, 4, false) : occ == 6 ? RT_WAVE_K(true, 6, false) : RT_WAVE_K(true, 5, false);
+#undef RT_WAVE_K
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s%s>", exact ? "EXACT" : "FMA", !exact && !csg ? ",NO_CSG" : "");
       block = rtd::WAVEPATH_THREADS;
-      dyn_lds = rtd::wave_lds_layout(L::SHAPES, L::MATERIALS, L::PIGMENTS, L::CSG_LEAVES, L::CSG_PATH, L::CSG_NODES, L::CSG_PROG, L::CSG_TOPS).total;
+      dyn_lds = (!exact && !csg) ? rtd::wave_lds_layout_for<false>().total : rtd::wave_lds_layout_for<true>().total;
       nodes_per_level = 64, stacks_per_block = rtd::WAVEPATH_WAVES, node_words = rtd::WAVE_NODE_WORDS;
     } else {
       path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);

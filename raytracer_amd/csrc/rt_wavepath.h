@@ -329,14 +329,21 @@ template <typename T> RT_DEV void stage_table_at(const T *&table, unsigned char 
   table = dst;
 }
 
-template <bool FAST, int WAVES_PER_SIMD>
+// The layout the kernel variant <.., CSG> uses, for the host's launch and the kernel itself: laid out for the LIMITS, not for
+// a scene's table sizes, so that the offsets are compile-time constants (immediate offsets of the ds_read instructions
+// instead of ~20 scalar registers of addresses; measured 2-3 %).  31 KB per workgroup with the CSG tables (5 workgroups per
+// CU), 25 KB without (6).
+template <bool CSG> constexpr WaveLdsLayout wave_lds_layout_for() {
+  using LIM = PathLdsLimits;
+  return wave_lds_layout(LIM::SHAPES, LIM::MATERIALS, LIM::PIGMENTS, CSG ? LIM::CSG_LEAVES : 0, CSG ? LIM::CSG_PATH : 0, CSG ? LIM::CSG_NODES : 0,
+                         CSG ? LIM::CSG_PROG : 0, CSG ? LIM::CSG_TOPS : 0);
+}
+
+// CSG = false: the variant for worlds without CSG objects (no evaluator code, no CSG tables: fewer registers, less LDS).
+template <bool FAST, int WAVES_PER_SIMD, bool CSG = true>
 __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_path_wave(Scene s, RenderParams p) {
   extern __shared__ __align__(16) unsigned char wave_lds[];
-  // the layout is laid out for the LIMITS, not for this scene's table sizes: the offsets are then compile-time constants
-  // (immediate offsets of the ds_read instructions instead of ~20 scalar registers of addresses; measured 2-3 %), and
-  // 31 KB per workgroup still lets 5 workgroups share a CU — all the register budget allows anyway
-  using LIM = PathLdsLimits;
-  constexpr WaveLdsLayout L = wave_lds_layout(LIM::SHAPES, LIM::MATERIALS, LIM::PIGMENTS, LIM::CSG_LEAVES, LIM::CSG_PATH, LIM::CSG_NODES, LIM::CSG_PROG, LIM::CSG_TOPS);
+  constexpr WaveLdsLayout L = wave_lds_layout_for<CSG>();
   {
     const int ns = p.tab_shapes, nm = p.tab_materials, np = p.tab_pigments;
     stage_table_at(s.shape_w2l, wave_lds, L.w2l, 12 * ns);
@@ -350,13 +357,15 @@ __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_pat
     stage_table_at(s.pigment_color1, wave_lds, L.pig_c1, 3 * np);
     stage_table_at(s.pigment_color2, wave_lds, L.pig_c2, 3 * np);
     stage_table_at(s.pigment_n_intervals, wave_lds, L.pig_n, np);
-    stage_table_at(s.csg_leaf, wave_lds, L.csg_leaf, p.tab_csg_leaves);
-    stage_table_at(s.csg_leaf_tt, wave_lds, L.csg_leaf_tt, p.tab_csg_leaves);
-    stage_table_at(s.csg_path, wave_lds, L.csg_path, p.tab_csg_path);
-    stage_table_at(s.csg_prog_range, wave_lds, L.csg_range, 4 * p.tab_csg_nodes);
-    stage_table_at(s.csg_op, wave_lds, L.csg_op, p.tab_csg_nodes);
-    stage_table_at(s.csg_prog, wave_lds, L.csg_prog, p.tab_csg_prog);
-    stage_table_at(s.csg_tops, wave_lds, L.csg_tops, s.n_csg_tops);
+    if constexpr (CSG) {
+      stage_table_at(s.csg_leaf, wave_lds, L.csg_leaf, p.tab_csg_leaves);
+      stage_table_at(s.csg_leaf_tt, wave_lds, L.csg_leaf_tt, p.tab_csg_leaves);
+      stage_table_at(s.csg_path, wave_lds, L.csg_path, p.tab_csg_path);
+      stage_table_at(s.csg_prog_range, wave_lds, L.csg_range, 4 * p.tab_csg_nodes);
+      stage_table_at(s.csg_op, wave_lds, L.csg_op, p.tab_csg_nodes);
+      stage_table_at(s.csg_prog, wave_lds, L.csg_prog, p.tab_csg_prog);
+      stage_table_at(s.csg_tops, wave_lds, L.csg_tops, s.n_csg_tops);
+    }
     if (FAST) { // the FMA code reads these two only for top-level shapes (make_hit_fast), where they equal the composed tables
       s.shape_inv = s.shape_w2l;
       s.shape_fwd = s.shape_l2w;
@@ -383,7 +392,7 @@ __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_pat
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
     if (B.active)
-      h = world_ray_intersection<FAST>(s, B.ray);
+      h = world_ray_intersection<FAST, CSG>(s, B.ray);
     RT_WSTAMP(ts2);
     B.shade(s, p, sh, h);
 #ifdef RT_PROFILE_PHASES
