@@ -403,7 +403,7 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 // separate translation units so that the ~30 kernels compile in parallel).
 const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
-const void *rt_tile_kernel(int waves); // rt_wide_tile.hip: k_render_path_tile<8, W>
+const void *rt_tile_kernel(int waves, bool csg); // rt_wide_tile.hip: k_render_path_tile<8, W, CSG>
 #ifndef RT_WAVE_OCC_NO_CSG
 #define RT_WAVE_OCC_NO_CSG 6
 #endif
@@ -1002,7 +1002,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
         if (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8)
           waves = w_env;
         block = 64u * static_cast<unsigned>(waves);
-        path_kernel = rt_tile_kernel(waves);
+        path_kernel = rt_tile_kernel(waves, sc->dev.n_csg_tops > 0);
         std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=8,W=%d>", waves);
       }
     }
