@@ -110,6 +110,7 @@ struct rt_scene {
   // what the world-space sphere filter's rounding error depends on (see world_filter_ok): the farthest register sphere from
   // the origin (|C| + r) and the smallest r^2 among them
   double wide_reach = 0.0, wide_rmin2 = 0.0;
+  bool csg_all_tt4 = false;      // every CSG tree has a truth table and at most 4 leaves
   DeviceBuffer samples, stack;   // grow-only scratch reused across renders
   DeviceBuffer frame;            // rt_render_frame_host: the frame while it is in HBM
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -739,6 +740,9 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.n_wide_lane = static_cast<int32_t>(wide_lane.size());
   S.n_planes = static_cast<int32_t>(planes.size());
   S.n_csg_tops = static_cast<int32_t>(cb.tops.size());
+  sc->csg_all_tt4 = !cb.tops.empty();
+  for (const rtd::CsgTop &top : cb.tops)
+    sc->csg_all_tt4 = sc->csg_all_tt4 && top.tt && top.leaf_end - top.leaf_begin <= 4;
   S.n_objects = static_cast<int32_t>(d->n_objects);
   UP(upload(sc, d->shape_fwd, 12 * static_cast<size_t>(d->n_shapes), &S.shape_fwd));
   UP(upload(sc, d->shape_inv, 12 * static_cast<size_t>(d->n_shapes), &S.shape_inv));
@@ -932,12 +936,15 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
 #define RT_WAVE_K(FAST, OCC, CSG) reinterpret_cast<const void *>(rtd::k_render_path_wave<FAST, OCC, CSG>)
       if (exact)
         path_kernel = RT_WAVE_K(false, 4, true);
+      else if (csg && sc->csg_all_tt4) // every tree has a truth table and at most 4 leaves (samples/csg_example.txt): that evaluator only
+        path_kernel = reinterpret_cast<const void *>(rtd::k_render_path_wave<true, 5, true, true>);
       else if (csg)
         path_kernel = occ == 4 ? RT_WAVE_K(true, 4, true) : occ == 6 ? RT_WAVE_K(true, 6, true) : RT_WAVE_K(true, 5, true);
       else
         path_kernel = occ == 4 ? RT_WAVE_K(true, 4, false) : occ == 6 ? RT_WAVE_K(true, 6, false) : RT_WAVE_K(true, 5, false);
 #undef RT_WAVE_K
-      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s%s>", exact ? "EXACT" : "FMA", !exact && !csg ? ",NO_CSG" : "");
+      std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wave<%s%s>", exact ? "EXACT" : "FMA",
+                    exact ? "" : !csg ? ",NO_CSG" : sc->csg_all_tt4 ? ",CSG_TT4" : "");
       block = rtd::WAVEPATH_THREADS;
       dyn_lds = (!exact && !csg) ? rtd::wave_lds_layout_for<false>().total : rtd::wave_lds_layout_for<true>().total;
       nodes_per_level = 64, stacks_per_block = rtd::WAVEPATH_WAVES, node_words = rtd::WAVE_NODE_WORDS;

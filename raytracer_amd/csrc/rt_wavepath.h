@@ -340,7 +340,8 @@ template <bool CSG> constexpr WaveLdsLayout wave_lds_layout_for() {
 }
 
 // CSG = false: the variant for worlds without CSG objects (no evaluator code, no CSG tables: fewer registers, less LDS).
-template <bool FAST, int WAVES_PER_SIMD, bool CSG = true>
+// TT4 = true: every CSG tree has a truth table and at most 4 leaves: only that evaluator is compiled in (fewer registers).
+template <bool FAST, int WAVES_PER_SIMD, bool CSG = true, bool TT4 = false>
 __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_path_wave(Scene s, RenderParams p) {
   extern __shared__ __align__(16) unsigned char wave_lds[];
   constexpr WaveLdsLayout L = wave_lds_layout_for<CSG>();
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_pat
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
     if (B.active)
-      h = world_ray_intersection<FAST, CSG>(s, B.ray);
+      h = world_ray_intersection<FAST, CSG, TT4>(s, B.ray);
     RT_WSTAMP(ts2);
     B.shade(s, p, sh, h);
 #ifdef RT_PROFILE_PHASES
