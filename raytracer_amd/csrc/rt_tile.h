@@ -9,13 +9,13 @@ namespace rtd {
 // Same pool, queue and finish as k_render_path_wide (rt_wide.h); what changes is who evaluates the filter
 //     b = O.u - C.u,   c = (O.O + k) - 2 O.C,   disc = b^2 - c          (u = D / |D|, k = C.C - r^2; see WideRayT<true>)
 // b and c are inner products of a per-ray vector with a per-sphere vector, so a block of rays against a block of spheres
-// is a small matrix product, and binary32 in / binary32 accumulate MFMAs compute exactly such fmaf chains at the VALU's
-// full fp32 rate, on a pipe of their own:
+// is a small matrix product, and binary32 in / binary32 accumulate MFMAs compute exactly such fmaf chains at the full fp32
+// rate of the SIMD (64 flop per cycle) with one instruction per 4096 flops:
 //     b[i][j] = sum_k A_b[i][k] B_b[k][j],   A_b = ( cx  cy  cz  1 ) per sphere i,   B_b = ( -ux  -uy  -uz  O.u ) per ray j
 //     c[i][j] = sum_k A_c[i][k] B_c[k][j],   A_c = ( cx  cy  cz  k ),               B_c = ( -2ox -2oy -2oz  1  )
-// two v_mfma_f32_32x32x2_f32 (K = 2 each) per product, four per 1024 tests = 256 matrix-pipe cycles per SIMD, against
-// 8 VALU instructions per 64 tests = 256+ VALU cycles for the same tests before.  O.O stays out of the product (it is the
-// ray's own constant): the VALU forms d = b^2 - c (16 fma per lane per tile) and asks d > O.O.
+// two v_mfma_f32_32x32x2_f32 (K = 2 each) per product, four per 1024 tests = 256 cycles per SIMD, against 8 VALU
+// instructions per 64 tests = 256 cycles at best (625 measured) for the same tests before.  O.O stays out of the product (it
+// is the ray's own constant): the VALU forms d = b^2 - c (16 fma per lane per tile) and asks d > O.O.
 //
 // Operand layout of the instruction (probed on the device, scripts/microbench/mfma_probe.hip): lane l supplies
 // A[i = l % 32][k = l / 32] and B[k = l / 32][j = l % 32]; register r of lane l receives D[i = 8 (r / 4) + 4 (l / 32) + r % 4]
@@ -28,7 +28,7 @@ namespace rtd {
 // worlds take several passes, the registers reloaded from L2 per pass).  Measured, N=512, W=1: S=4 9822, S=8 9926, S=16 8900
 // Mrays/s (at 16 the lane state that shading needs is spilled around the scan); 5 waves per SIMD (96 VGPRs): 8950.
 //
-// What it buys (N=512 1080p AA=4 / the 68-row slice of N=4096): 7.60 -> 9.93 and 1.02 -> 1.40 Grays/s over the VALU filter of
+// What it buys (N=512 1080p AA=4 / a 1/16 slice of the N=4096 frame): 7.60 -> 9.94 and 1.02 -> 1.46 Grays/s over the VALU filter of
 // rt_wide.h.  The binary32 MFMA and the VALU share the SIMD's fp32 lanes (scripts/microbench/mfma_probe.hip: 4 MFMAs alone
 // take 278 cycles per tile, + 24 VALU instructions 345, + 72 459 — the times add, they do not overlap), so the gain is not a
 // second pipe but instruction efficiency: the 4 MFMAs carry 16 of the 18 flops per test at the full rate of 64 per cycle and
