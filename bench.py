@@ -350,7 +350,7 @@ def main():
             "kernel_ms_per_step_max_rank": kernel_ms_max,
             "gather_ms_per_step": {"rank0_including_wait_for_slowest_rank": gather_ms, "min_over_ranks": float(g[0])},
             # dominant kernel on rank 0's share: ITS rays / ITS duration (k_resolve rides in the same interval, < 0.1 %)
-            "roofline": roofline_block(census, kernel_name, rays_local, kernel_ms, pmc_traffic(args), bvh=args.bvh),
+            "roofline": roofline_block(census, kernel_name, rays_local, kernel_ms, pmc_traffic(args) if world_size == 1 else None, bvh=args.bvh),
         }
         import hashlib
         # the assembled frame is bit-identical for any number of ranks: compare this across --gpus runs
