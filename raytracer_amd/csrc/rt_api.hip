@@ -405,6 +405,12 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
 const void *rt_tile_kernel(int waves, bool csg); // rt_wide_tile.hip: k_render_path_tile<8, W, CSG>
+// From how many register spheres on the large-world kernels replace the per-lane scan of the small-world kernel.  Measured
+// with the tile kernel (synthetic worlds, 960x540 AA=4, frame ms tile | per-lane): 16 spheres 17.2 | 9.8, 24: 20.5 | 19.2,
+// 32: 26.6 | 27.5, 48: 26.2 | 27.5, 64: 25.7 | 26.6 — one full tile of 32 is the break-even.
+#ifndef RT_WIDE_MIN_SPHERES
+#define RT_WIDE_MIN_SPHERES 32
+#endif
 #ifndef RT_WAVE_OCC_NO_CSG
 #define RT_WAVE_OCC_NO_CSG 6
 #endif
@@ -921,7 +927,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const bool small_tables = tab[0] <= L::SHAPES && tab[1] <= L::MATERIALS && tab[2] <= L::PIGMENTS && tab[3] <= L::CSG_LEAVES &&
                               tab[4] <= L::CSG_PATH && tab[5] <= L::CSG_NODES && tab[6] <= L::CSG_PROG && sc->dev.n_csg_tops <= L::CSG_TOPS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
-    const bool use_wide = !exact && !use_bvh && sc->dev.n_wide >= 64; // measured: from 64 spheres in the register rows on, the wide kernel beats the per-lane scan
+    static const int wide_min = [] { const char *e = std::getenv("RT_WIDE_MIN"); return e && *e ? std::atoi(e) : RT_WIDE_MIN_SPHERES; }(); // tuning aid
+    const bool use_wide = !exact && !use_bvh && sc->dev.n_wide >= wide_min; // measured: see RT_WIDE_MIN_SPHERES
     // Small worlds with small lookup tables (every sample scene of the reference): the pool run wave by wave (rt_wavepath.h)
     const bool use_wave = small_tables && !use_bvh && !use_wide;
     int nodes_per_level = 0, stacks_per_block = 1, node_words = rtd::NODE_WORDS; // nodes_per_level 0: the block size, set below

@@ -1,4 +1,4 @@
-// rt_wavepath.h — the path kernel for SMALL worlds (fewer than 64 top-level spheres: the reference's sample scenes,
+// rt_wavepath.h — the path kernel for SMALL worlds (fewer than 32 register spheres: the reference's sample scenes,
 // BASELINE configs 3 and 4): the node pool of rt_path.h run by ONE WAVE instead of a workgroup.
 //
 // Why: with a few objects a ray is ~500 instructions, and the workgroup pool spent more time meeting at barriers

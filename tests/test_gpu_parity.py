@@ -228,9 +228,9 @@ def test_error_behaviour(worlds, scenes):
         DeviceWorld(broken)
 
 
-# ---- the wide path kernel (worlds with >= 64 top-level spheres: spheres in registers, rays through LDS) ----
-# sphere counts cover: leftover scanned per lane (77 -> 78 = 64 + 14), partly empty last row (100, 90), several waves
-# per workgroup (1100: 2 waves, 4000: 8 waves)
+# ---- the large-world path kernels (worlds with >= 32 register spheres: spheres in registers, rays through LDS) ----
+# sphere counts cover: the smallest worlds that take them (33, 40, 45: one full tile / row and a bit), leftover scanned per
+# lane (77 -> 78 = 64 + 14), partly empty last tile / row (100, 90), several waves per workgroup (600: 2, 1100 and 4000: 4)
 
 def _ellipsoid_world(n, seed=5):
     """n random ellipsoids (rotated, non-uniformly scaled: the general affine register form) + floor + sky."""
@@ -252,7 +252,8 @@ def _ellipsoid_world(n, seed=5):
     return b.build()
 
 
-@pytest.mark.parametrize("kind,n", [("iso", 600), ("iso", 1100), ("general", 700), ("iso", 77), ("iso", 100), ("general", 90), ("iso", 4000)])
+@pytest.mark.parametrize("kind,n", [("iso", 600), ("iso", 1100), ("general", 700), ("iso", 77), ("iso", 100), ("general", 90), ("iso", 4000),
+                                    ("iso", 33), ("iso", 40), ("general", 45)])
 def test_path_wide_kernel_same_streams_vs_oracle(kind, n):
     """Same per-sample streams on the wide kernel and on the CPU oracle -> the same paths (FMA / world-space
     sphere arithmetic moves t by ulps, so a few paths diverge at discontinuities)."""
