@@ -97,7 +97,7 @@ def pmc_traffic(args):
     (scripts/pmc_run.sh -> profiles/r2/n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, each in its own rocprofv3 --pmc
     pass, summed over the launches of one run and divided by their number).  None for any other configuration:
     counters cannot be read from inside the timed run."""
-    default = (not args.bvh and args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
+    default = (not args.bvh and not args.valu_only and args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
                and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
     if not default:
         return None
@@ -203,6 +203,10 @@ def measure_configs(device, log):
         note="whole-frame estimate = 16 x kernel_ms (slices differ by < 1 %, profiles/r1/h_full_n4096_1080p_aa4.json); "
              "configs[4]'s 3840x2160 frame is 64 slices of this cost")
     recs[-1]["frame_ms_estimate_one_gpu"] = 16.0 * recs[-1]["kernel_ms"]
+    # The headline workload once more WITHOUT any MFMA instruction (BASELINE.json's north_star expected no dense contraction
+    # in this path; the brute-force ray x sphere filter turned out to be one): the vector-ALU filter kernel.
+    run("N512-valu-only", "the bench default (synthetic 512-sphere scene, path 10/3/5, 1920x1080, AA=4) with RT_FLAG_VALU_ONLY: "
+        "the sphere filter on the vector ALU, no matrix-core instruction", synthetic_scene(512)[0], RenderMode("path", valu_only=True), 1920, 1080, 4, reps=1)
     return recs
 
 
@@ -226,6 +230,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1-C5) of the N=1 line")
     ap.add_argument("--bvh", action="store_true",
                     help="RT_FLAG_ACCEL_BVH: not the reference's algorithmic work, so the line carries no roofline fraction")
+    ap.add_argument("--valu-only", action="store_true", help="RT_FLAG_VALU_ONLY: the large-world sphere filter on the vector ALU (no MFMA instruction)")
     ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices, gather staged through the host)")
@@ -263,7 +268,7 @@ def main():
         scene, text = synthetic_scene(args.spheres)
     world = DeviceWorld(scene, dev_index)
     tracer = GpuImageTracer(args.width, args.height, scene.camera, args.aa)
-    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh)
+    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh, valu_only=args.valu_only)
     rows = rank_rows(args.height, rank, world_size)
     local = torch.empty((rows.n_local_rows, args.width, 3), dtype=torch.float32, device=device)
     full = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None

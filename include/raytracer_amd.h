@@ -64,6 +64,7 @@ enum { RT_RNG_PER_NODE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
 #define RT_FLAG_EXACT_ARITHMETIC 1u
 #define RT_FLAG_OBJECT_SPACE_SPHERES 2u
 #define RT_FLAG_ACCEL_BVH 4u
+#define RT_FLAG_VALU_ONLY 8u
 
 /* Limits of the device CSG evaluator (fixed-capacity, no heap). */
 #define RT_MAX_CSG_DEPTH 8    /* nesting depth of CSG nodes below one top-level object */
@@ -184,6 +185,9 @@ typedef struct rt_render_cfg {
    * hierarchy built at rt_scene_create instead of testing every sphere (the reference has no such
    * structure: World::ray_intersection is a linear scan).  Same hits, same tie rule, far fewer tests on
    * worlds with thousands of spheres; planes and CSG objects are still tested one by one.
+   * RT_FLAG_VALU_ONLY: path mode on large worlds evaluates the sphere filter with vector-ALU instructions only
+   * (k_render_path_wide) instead of on the fp32 matrix cores (k_render_path_tile, the default: same arithmetic form,
+   * same fp32 lanes, fewer instructions).  For measurement: the configuration without any MFMA instruction.
    */
   uint32_t flags;
 } rt_render_cfg;

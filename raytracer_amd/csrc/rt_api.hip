@@ -1003,8 +1003,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       block = 64u * static_cast<unsigned>(waves);
       path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wide<%s,K=%d,W=%d>", iso ? "ISO" : "GEN", k, waves);
-      static const bool no_tile = [] { const char *e = std::getenv("RT_NO_TILE"); return e && *e; }(); // tuning aid: the VALU filter instead of the MFMA one
-      if (iso && !no_tile) {
+      if (iso && !(cfg->flags & RT_FLAG_VALU_ONLY)) {
         // The filter on the matrix cores (rt_tile.h): 8 tiles of 32 spheres per wave and pass.  Waves per workgroup, measured
         // (Mrays/s; N=512: W=1 9926, W=2 9647 with S=4; N=1024: 5169 / 5244; N=4096: W=1 1215, 2 1271, 4 1402, 8 1350): 1 up to
         // 16 tiles, 2 up to 32, 4 beyond — small workgroups wait less at their barriers, until the passes get too many.

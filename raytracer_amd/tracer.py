@@ -35,6 +35,7 @@ class RenderMode:
     exact: bool = False                          # path mode: unfused reference-order arithmetic in the scan
     object_space_spheres: bool = False           # path mode, large worlds: never use the world-space sphere form
     bvh: bool = False                            # path mode: closest sphere through a BVH instead of the linear scan
+    valu_only: bool = False                      # path mode, large worlds: the sphere filter on the vector ALU, no MFMA instruction
 
 
 @dataclass
@@ -185,7 +186,7 @@ class GpuImageTracer:
         cfg.n_local_rows = rows.n_local_rows
         cfg.flags = (abi.RT_FLAG_EXACT_ARITHMETIC if mode.exact else 0) | \
             (abi.RT_FLAG_OBJECT_SPACE_SPHERES if mode.object_space_spheres else 0) | \
-            (abi.RT_FLAG_ACCEL_BVH if mode.bvh else 0)
+            (abi.RT_FLAG_ACCEL_BVH if mode.bvh else 0) | (abi.RT_FLAG_VALU_ONLY if mode.valu_only else 0)
         return cfg
 
     def fire_all_rays(self, world: DeviceWorld, mode: RenderMode, rows: RowBands | None = None, out=None,

@@ -116,3 +116,27 @@ def test_furnace_identity_at_full_sphere_counts(n):
         assert img.max() == np.float32(1.9375) and img.min() >= 1.9375 * 0.98
         assert (img != np.float32(1.9375)).any(axis=2).mean() <= 1e-3
     world.close()
+
+
+@pytest.mark.gpu
+def test_valu_only_flag_selects_the_kernel_without_matrix_instructions(big_scenes):
+    """RT_FLAG_VALU_ONLY: the same world-space filter evaluated by vector-ALU instructions (rt_wide.h) instead of the fp32
+    MFMA (rt_tile.h).  Same streams, same exact winner record: the two frames are two runs of the same estimator that differ
+    only where the filters' roundings rank near-equal candidates differently — a few pixels — and both sit on the oracle."""
+    from raytracer_amd import abi
+    from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
+    scene = big_scenes[512]
+    world = DeviceWorld(scene)
+    tr = GpuImageTracer(64, 36, scene.camera, 1)
+    kw = dict(n_rays=3, roulette=2, max_depth=3, seq_number=21)
+    tile = tr.fire_all_rays(world, RenderMode("path", **kw))
+    assert tr.last_stats.kernel.decode() == "k_render_path_tile<S=8,W=1>"
+    valu = tr.fire_all_rays(world, RenderMode("path", valu_only=True, **kw))
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_wide<ISO")
+    world.close()
+    want, _ = O.render(scene, O.make_cfg(64, 36, "path", spp_edge=1, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))
+    for name, got in (("tile", tile), ("valu", valu)):
+        off = (np.abs(got - want).max(axis=-1) > 1e-4).mean()
+        print(f"{name}: {100 * off:.2f} % of pixels off the oracle's same-stream frame")
+        assert off <= 0.04
+    assert (np.abs(tile - valu).max(axis=-1) > 1e-4).mean() <= 0.04
