@@ -24,13 +24,14 @@ for spec in sys.argv[1:]:
     print(spec, flush=True)
     variants = [("default", {}), ("exact", dict(exact=True))]
     if kind == "synth":
-        variants += [("objspace", dict(object_space_spheres=True)), ("bvh", dict(bvh=True))]
+        variants += [("valu-only", dict(valu_only=True)), ("objspace", dict(object_space_spheres=True)), ("bvh", dict(bvh=True))]
     for label, kw in variants:
         ms, rays = [], []
-        for seed in range(100, 108):
+        for seed in range(100, 100 + int(os.environ.get("BIAS_SEEDS", "8"))):
             img = tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=seed, **kw)).astype(np.float64)
             ms.append(img.mean())
             rays.append(int(tr.last_stats.rays))
+            print(f"    [{label} seed {seed}: {tr.last_stats.kernel_ms:.0f} ms]", file=sys.stderr, flush=True)
         ms = np.array(ms)
         print(f"  {label:9s} {tr.last_stats.kernel.decode():34s} mean {ms.mean():.6f} +- {ms.std(ddof=1) / np.sqrt(len(ms)):.6f}  rays {np.mean(rays):.5g}", flush=True)
     world.close()
