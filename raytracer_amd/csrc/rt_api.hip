@@ -1088,6 +1088,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     if (c[7])
       std::fprintf(stderr, "[rt phases] blocks*iters=%llu rays/iter=%.1f cycles/iter: queue=%.0f scan=%.0f shade=%.0f (100 MHz ticks x?)\n", c[7],
                    double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]));
+    if (c[7] && c[9])
+      std::fprintf(stderr, "[rt phases] of shade: finish (lane spheres, planes, exact record) = %.0f\n", double(c[9]) / double(c[7]));
 #endif
 #ifdef RT_BVH_STATS
     if (c[8])

@@ -83,7 +83,14 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
   PathBlock<T, true> L;
   L.init(p, sh);
 
+#ifdef RT_PROFILE_PHASES
+  unsigned long long t_queue = 0, t_scan = 0, t_finish = 0, t_shade = 0, n_iter = 0, n_rays_q = 0;
+#define RT_TSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define RT_TSTAMP(var)
+#endif
   for (;;) {
+    RT_TSTAMP(ts0);
     // -- every lane gets a ray from the workgroup's node pool; the live rays are queued (compacted) ----
     if (threadIdx.x == 0)
       q_count = 0;
@@ -104,6 +111,7 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
     }
     __syncthreads();
     const int n_q = q_count;
+    RT_TSTAMP(ts1);
 
     // -- the filter: every wave takes the queued rays 32 at a time against its sphere tiles -------------
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -185,8 +193,14 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
       }
     }
     __syncthreads();
+    RT_TSTAMP(ts2);
 
     // -- every lane is a ray again: finish the query, shade, produce the next ray -------------------
+    // (Phase split per iteration of a one-wave workgroup at N=512, -DRT_PROFILE_PHASES: deal + queue 11.2 k cycles, filter
+    // 33.3 k, this finish 11.2 k, shade 6.2 k; at N=4096, W=4: 19 k / 333 k / 15 k / 15 k.  The finish is a chain of dependent
+    // trips to memory: position -> ids -> matrices -> shading record.  Fetching the winner's matrices and shading record by
+    // position in one trip was built and measured: the 36-52 registers it holds push the phase into scratch — 74-114 spilled
+    // registers, finish 11.2 k -> 15.4 k cycles, frame 9960 -> 9416 Mrays/s — and was not kept.)
     Hit h;
     h.object = h.shape = -1;
     h.t = 0.f;
@@ -211,8 +225,23 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
       }
       h = world_finish_hit<true, true, CSG>(s, L.ray, best);
     }
+    RT_TSTAMP(ts3);
     L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
+#ifdef RT_PROFILE_PHASES
+    RT_TSTAMP(ts4);
+    t_queue += ts1 - ts0, t_scan += ts2 - ts1, t_finish += ts3 - ts2, t_shade += ts4 - ts3, n_iter += 1, n_rays_q += n_q;
+#endif
   }
+#ifdef RT_PROFILE_PHASES
+  if (threadIdx.x == 0) { // counters 4-8 as the wide kernel reports them (finish + shade together) and the finish share apart
+    atomicAdd(p.counters + 4, t_queue);
+    atomicAdd(p.counters + 5, t_scan);
+    atomicAdd(p.counters + 6, t_finish + t_shade);
+    atomicAdd(p.counters + 7, n_iter);
+    atomicAdd(p.counters + 8, n_rays_q);
+    atomicAdd(p.counters + 9, t_finish);
+  }
+#endif
   wave_add_tally(p.counters, 0, L.rays);
 }
 
