@@ -96,9 +96,6 @@ constexpr int PATH_THREADS = 256;
 // CSG leaf / chain / program tables — is staged in LDS, and the Scene copy the workgroup uses points there.  The chains
 // of dependent trips to L2 (hit record -> shading record -> material -> pigment; CSG leaf -> chain -> program -> shape)
 // become LDS reads.
-struct PathLdsLimits {
-  static constexpr int SHAPES = 64, MATERIALS = 32, PIGMENTS = 64, CSG_LEAVES = 32, CSG_PATH = 128, CSG_NODES = 32, CSG_PROG = 128, CSG_TOPS = 8;
-};
 template <typename T> RT_DEV void stage_table(const T *&table, T *lds, int n) {
   for (int i = threadIdx.x; i < n; i += PATH_THREADS)
     lds[i] = table[i];

@@ -82,6 +82,10 @@ RT_DEV void wave_add_tally(unsigned long long *counters, int which, unsigned lon
 // deeper node is used up, hence at most T nodes per depth level: capacity T * max_depth (T if n_rays
 // is 1, where a node is used up by the one lane that takes it).
 // ---------------------------------------------------------------------------------------------
+// Table sizes up to which the small-world kernels stage a scene's lookup tables in LDS (rt_kernels.h, rt_wavepath.h).
+struct PathLdsLimits {
+  static constexpr int SHAPES = 64, MATERIALS = 32, PIGMENTS = 64, CSG_LEAVES = 32, CSG_PATH = 128, CSG_NODES = 32, CSG_PROG = 128, CSG_TOPS = 8;
+};
 constexpr int NODE_WORDS = 14; // point(3) vec(3) weight(3) key(2) meta(1) remaining(1) shape-hit(1)
 constexpr int SAMPLE_CHUNK = 2; // pixel samples fetched from the call's queue per top-up, in units of T
 

@@ -1,6 +1,9 @@
 // rt_tile.h — the path kernel for large worlds of translation * uniform-scaling spheres: the closest-hit FILTER on the
 // matrix cores (v_mfma_f32_32x32x2_f32), 32 rays x 32 spheres per tile.
 #pragma once
+#include <type_traits>
+
+#include "rt_wavepath.h"
 #include "rt_wide.h"
 
 namespace rtd {
@@ -75,13 +78,20 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
   __shared__ TileRay q_ray[T];
   __shared__ unsigned long long q_key[T];
   __shared__ int q_count;
-  __shared__ PathShared<T> sh;
+  // The pool of rt_path.h; a one-wave workgroup runs it as the small-world kernel does (rt_wavepath.h: no barriers, prefix
+  // sums in DPP, one 64-byte record per node) — dealing and shading were 28 % of its iteration with the workgroup pool.
+  using Pool = std::conditional_t<W == 1, WavePath<true>, PathBlock<T, true>>;
+  using PoolShared = std::conditional_t<W == 1, WaveShared, PathShared<T>>;
+  __shared__ PoolShared sh;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
   const int n_tiles = s.n_wide_tiles;
   const int n_pass = (n_tiles + S * W - 1) / (S * W);
-  PathBlock<T, true> L;
-  L.init(p, sh);
+  Pool L;
+  if constexpr (W == 1)
+    L.init(p, sh, blockIdx.x);
+  else
+    L.init(p, sh);
 
 #ifdef RT_PROFILE_PHASES
   unsigned long long t_queue = 0, t_scan = 0, t_finish = 0, t_shade = 0, n_iter = 0, n_rays_q = 0;

@@ -24,7 +24,7 @@
 
 namespace rtd {
 
-constexpr int WAVE_NODE_WORDS = 16; // point(3) depth-and-slot(1) | vec(3) children-left(1) | weight(3) pad(1) | key(2) pad(2)
+constexpr int WAVE_NODE_WORDS = 16; // point(3) depth-and-slot(1) | vec(3) children-left(1) | weight(3) shape-hit(1) | key(2) pad(2)
 
 struct WaveShared {              // LDS state of one wave: 3712 bytes
   unsigned long long acc[64][3]; // per sample slot: fixed-point radiance
@@ -79,6 +79,7 @@ template <bool FAST> struct WavePath {
   Pcg pcg;
   V3 throughput;
   int depth, slot;
+  int origin_shape; // the shape this ray leaves (-1: a camera ray); read by the large-world kernel (rt_tile.h) only
   uint32_t rays;
   // wave state (uniform: scalar registers)
   int top, n_free, res_count, exhausted;
@@ -96,6 +97,7 @@ template <bool FAST> struct WavePath {
     pcg.inc = (p.seq_number << 1u) | 1u;
     throughput = mk3(1.f, 1.f, 1.f);
     depth = slot = 0;
+    origin_shape = -1;
     rays = 0;
     top = 0, n_free = 64, res_count = 0, exhausted = 0, res_base = 0;
     cap = p.pool_cap;
@@ -173,6 +175,7 @@ template <bool FAST> struct WavePath {
       ray.o = mk3(a.x, a.y, a.z);
       const V3 vec = mk3(b.x, b.y, b.z);
       throughput = mk3(c.x, c.y, c.z);
+      origin_shape = __float_as_int(c.w);
       if (meta >> 31) { // SpecularBRDF: every child is the mirror ray, no draw
         ray.d = vec;
         ray.tmin = 1.e-5f;
@@ -196,6 +199,7 @@ template <bool FAST> struct WavePath {
       ray = primary_ray(p, sid);
       pcg.state = node_root_key(p.seq_number, sid.global);
       depth = 0;
+      origin_shape = -1;
       throughput = mk3(1.f, 1.f, 1.f);
       active = true;
     }
@@ -271,7 +275,7 @@ template <bool FAST> struct WavePath {
       float4 *rec = pool + 4 * (size_t)node;
       rec[0] = make_float4(h.point.x, h.point.y, h.point.z, __uint_as_float((uint32_t)slot | ((uint32_t)(depth + 1) << 16) | ((uint32_t)brdf << 31)));
       rec[1] = make_float4(vec.x, vec.y, vec.z, __int_as_float(p.n_rays));
-      rec[2] = make_float4(weight.x, weight.y, weight.z, 0.f);
+      rec[2] = make_float4(weight.x, weight.y, weight.z, __int_as_float(h.shape));
       rec[3] = make_float4(__uint_as_float((uint32_t)pcg.state), __uint_as_float((uint32_t)(pcg.state >> 32)), 0.f, 0.f);
       if (cap <= 8 * 64)
         sh.rem[node] = (unsigned short)p.n_rays;
