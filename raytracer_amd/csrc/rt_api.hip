@@ -1016,8 +1016,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
           waves = w_env;
         block = 64u * static_cast<unsigned>(waves);
         path_kernel = rt_tile_kernel(waves, sc->dev.n_csg_tops > 0);
-        if (waves == 1) // the one-wave shape runs the wave pool (rt_wavepath.h): one stack of 64-byte records per workgroup
-          nodes_per_level = 64, stacks_per_block = 1, node_words = rtd::WAVE_NODE_WORDS;
+        nodes_per_level = 64, stacks_per_block = waves, node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave (rt_wavepath.h)
         std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=8,W=%d>", waves);
       }
     }

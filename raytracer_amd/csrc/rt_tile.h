@@ -77,22 +77,21 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
   constexpr int T = 64 * W;
   __shared__ TileRay q_ray[T];
   __shared__ unsigned long long q_key[T];
-  __shared__ int q_count;
-  // The pool of rt_path.h; a one-wave workgroup runs it as the small-world kernel does (rt_wavepath.h: no barriers, prefix
-  // sums in DPP, one 64-byte record per node) — dealing and shading were 28 % of its iteration with the workgroup pool.
-  using Pool = std::conditional_t<W == 1, WavePath<true>, PathBlock<T, true>>;
-  using PoolShared = std::conditional_t<W == 1, WaveShared, PathShared<T>>;
-  __shared__ PoolShared sh;
+  __shared__ int q_cnt[W], q_live[W]; // per wave: rays queued this iteration, pool not yet dry
+  // The pool of rt_path.h, one per WAVE, run as the small-world kernel runs it (rt_wavepath.h: no barriers, prefix sums in
+  // DPP, one 64-byte record per node).  The waves of a workgroup share the ray queue and the sphere tiles, nothing else:
+  // they meet twice per iteration, around the filter.  Every wave queues into its OWN 64 slots (q_ray / q_key / q_cnt /
+  // q_live [wave]) and nobody else ever writes them outside the filter, so a wave that is still reading its results may be
+  // overtaken by one already queueing its next rays.  Measured against one pool per workgroup (PathBlock): N=512 (W=1)
+  // 9.94 -> 10.58 Grays/s — dealing and shading were 28 % of an iteration.
+  __shared__ WaveShared sh_all[W];
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  WaveShared &sh = sh_all[wave];
   const int n_tiles = s.n_wide_tiles;
   const int n_pass = (n_tiles + S * W - 1) / (S * W);
-  Pool L;
-  if constexpr (W == 1)
-    L.init(p, sh, blockIdx.x);
-  else
-    L.init(p, sh);
-
+  WavePath<true> L;
+  L.init(p, sh, blockIdx.x * W + wave);
 #ifdef RT_PROFILE_PHASES
   unsigned long long t_queue = 0, t_scan = 0, t_finish = 0, t_shade = 0, n_iter = 0, n_rays_q = 0;
 #define RT_TSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -101,26 +100,28 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
 #endif
   for (;;) {
     RT_TSTAMP(ts0);
-    // -- every lane gets a ray from the workgroup's node pool; the live rays are queued (compacted) ----
-    if (threadIdx.x == 0)
-      q_count = 0;
-    if (!L.deal(s, p, sh)) // synchronises the workgroup
-      break;
+    // -- every lane gets a ray from its wave's node pool; the live rays of the workgroup are queued (compacted) ----
+    // A wave whose pool has run dry keeps coming along (its sphere tiles are part of every ray's scan) until all have.
+    const bool wave_live = L.deal(s, p, sh);
+    const unsigned long long live = __ballot(L.active);
+    if (lane == 0)
+      q_cnt[wave] = __popcll(live), q_live[wave] = wave_live ? 1 : 0;
     int my_q = -1;
     if (L.active) {
-      const unsigned long long live = __ballot(1);
-      const int rank = __popcll(live & ((1ull << lane) - 1ull));
-      int base = 0;
-      if (rank == 0)
-        base = atomicAdd(&q_count, __popcll(live));
-      base = __shfl(base, __ffsll((long long)live) - 1, 64);
-      my_q = base + rank;
+      my_q = 64 * wave + __popcll(live & ((1ull << lane) - 1ull));
       const int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
       q_ray[my_q] = TileRay::make(L.ray, self);
       q_key[my_q] = ~0ull;
     }
     __syncthreads();
-    const int n_q = q_count;
+    int n_q = 0, any_live = 0; // uniform
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      n_q += __builtin_amdgcn_readfirstlane(q_cnt[w]);
+      any_live |= __builtin_amdgcn_readfirstlane(q_live[w]);
+    }
+    if (!any_live)
+      break;
     RT_TSTAMP(ts1);
 
     // -- the filter: every wave takes the queued rays 32 at a time against its sphere tiles -------------
@@ -136,12 +137,16 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
         const float *rec = s.wide_tiles + (size_t)tile * 192 + lane;
         a1[s_] = rec[0], a2[s_] = rec[64], a3[s_] = rec[128];
       }
-      for (int r0 = 0; r0 < n_q; r0 += 32) {
-        const int n = r0 + col;
-        const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[min(n, n_q - 1)]);
+      for (int rt = 0; rt < 2 * W; ++rt) { // the two 32-ray blocks of every wave's slots
+        const int n_w = __builtin_amdgcn_readfirstlane(q_cnt[rt >> 1]), r0 = (rt & 1) * 32;
+        if (r0 >= n_w)
+          continue;
+        const int n = 64 * (rt >> 1) + r0 + col;
+        const bool valid = r0 + col < n_w;
+        const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[valid ? n : 64 * (rt >> 1)]);
         const float4 qa = rec[half], qc = rec[2];
         const float bq1 = qa.x, bq2 = qa.y, cq1 = qa.z, cq2 = half ? 1.f : qa.w;
-        const float oo = n < n_q ? qc.x : INF_F; // a lane past the queue's end asks d > +inf
+        const float oo = valid ? qc.x : INF_F; // a lane past the queue's end asks d > +inf
         const float tmin_u = qc.y, inv_len = qc.z;
         const int self = __float_as_int(qc.w);
         unsigned long long best = ~0ull;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
       h = world_finish_hit<true, true, CSG>(s, L.ray, best);
     }
     RT_TSTAMP(ts3);
-    L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
+    L.shade(s, p, sh, h); // the wave's own pool: no barrier; q_ray / q_key slots are rewritten only after the next deal
 #ifdef RT_PROFILE_PHASES
     RT_TSTAMP(ts4);
     t_queue += ts1 - ts0, t_scan += ts2 - ts1, t_finish += ts3 - ts2, t_shade += ts4 - ts3, n_iter += 1, n_rays_q += n_q;
