@@ -1005,8 +1005,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wide<%s,K=%d,W=%d>", iso ? "ISO" : "GEN", k, waves);
       if (iso && !(cfg->flags & RT_FLAG_VALU_ONLY)) {
         // The filter on the matrix cores (rt_tile.h): 8 tiles of 32 spheres per wave and pass.  Waves per workgroup, measured
-        // (Mrays/s; N=512: W=1 9926, W=2 9647 with S=4; N=1024: 5169 / 5244; N=4096: W=1 1215, 2 1271, 4 1402, 8 1350): 1 up to
-        // 16 tiles, 2 up to 32, 4 beyond — small workgroups wait less at their barriers, until the passes get too many.
+        // (Mrays/s at W = 1 / 2 / 4 / 8; N=512: 10723 / 10261 / 9839 / 8894; N=1024: 5366 / 5446 / 5585 / 5207; N=4096: 1275 /
+        // 1270 / 1403 / 1373): 1 up to 16 tiles, 2 up to 32, 4 beyond — small workgroups wait less at their two barriers, until
+        // the passes (sphere registers reloaded from L2) get too many.
         const int tiles = sc->dev.n_wide_tiles;
         static const int w_env = [] { const char *e = std::getenv("RT_TILE_W"); return e && *e ? std::atoi(e) : 0; }(); // tuning aid
         waves = 1;
