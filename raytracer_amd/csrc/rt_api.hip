@@ -968,8 +968,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       p.bvh_iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) ? 1 : 0;
       const bool want_leaves = !exact && p.bvh_iso;
       // per workgroup besides the tree: one 8-byte key per ray and 64 donor lanes per wave (rt_bvh.h) = 12 bytes per lane
-      const size_t room256 = (40 * 1024 - sizeof(rtd::PathShared<256>) - 512 - 12 * 256) / sizeof(rtd::BvhNode);
-      const size_t room512 = (72 * 1024 - sizeof(rtd::PathShared<512>) - 512 - 12 * 512) / sizeof(rtd::BvhNode);
+      const size_t room256 = (40 * 1024 - 4 * sizeof(rtd::WaveShared) - 512 - 12 * 256) / sizeof(rtd::BvhNode);
+      const size_t room512 = (72 * 1024 - 8 * sizeof(rtd::WaveShared) - 512 - 12 * 512) / sizeof(rtd::BvhNode);
       block = n_nodes + (want_leaves ? n_small : 0) <= room256 ? 256u : 512u;
       const size_t room = block == 256 ? room256 : room512;
       p.bvh_lds_nodes = static_cast<int32_t>(std::min(n_nodes, room));
@@ -986,6 +986,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
 #undef RT_BVH_PICK
 #undef RT_BVH_K
       dyn_lds = static_cast<size_t>(p.bvh_lds_nodes + p.bvh_lds_spheres) * sizeof(rtd::BvhNode) + 12 * static_cast<size_t>(block);
+      nodes_per_level = 64, stacks_per_block = static_cast<int>(block / 64), node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave
       if (dyn_lds > 32 * 1024) // above what a kernel gets without asking
         RT_HIP(hipFuncSetAttribute(path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn_lds)));
     }

@@ -17,7 +17,7 @@
 //   * lanes of a wave that run out of work take over pending subtrees of the lanes that still have some
 //     (bvh_closest_sphere).
 #pragma once
-#include "rt_path.h"
+#include "rt_wavepath.h"
 
 namespace rtd {
 
@@ -339,7 +339,7 @@ RT_DEV void bvh_closest_sphere(const Scene &s, const RenderParams &p, const Ray 
 template <bool FAST, int T, bool SPLIT, bool LEAF_LDS>
 __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams p) {
   extern __shared__ uint4 bvh_lds[];
-  __shared__ PathShared<T> sh;
+  __shared__ WaveShared sh_all[T / 64]; // one wave-run pool per wave (rt_wavepath.h): after the staging below the waves never meet
   for (int i = threadIdx.x; i < p.bvh_lds_nodes; i += T)
     bvh_lds[i] = reinterpret_cast<const uint4 *>(s.bvh)[i];
   if (LEAF_LDS)
@@ -348,8 +348,10 @@ __global__ void __launch_bounds__(T, 4) k_render_path_bvh(Scene s, RenderParams 
   const int wave = (int)(threadIdx.x >> 6);
   unsigned long long *const res = reinterpret_cast<unsigned long long *>(bvh_lds + p.bvh_lds_nodes + p.bvh_lds_spheres) + 64 * wave;
   int *const donor_lane = reinterpret_cast<int *>(bvh_lds + p.bvh_lds_nodes + p.bvh_lds_spheres + T / 2) + 64 * wave;
-  PathBlock<T, FAST> B;
-  B.init(p, sh); // synchronises the workgroup
+  WaveShared &sh = sh_all[wave];
+  WavePath<FAST> B;
+  B.init(p, sh, (int)blockIdx.x * (T / 64) + wave);
+  __syncthreads(); // the tree is in LDS
   BvhStats st{};
   while (B.deal(s, p, sh)) {
     // FAST: the sphere a ray leaves is kept out of the fused tests and tested with the reference's arithmetic below

@@ -211,7 +211,7 @@ template <bool FAST> struct WavePath {
 
   // PathTracer::operator() steps 2-6 for the node whose closest hit is `h` (see PathBlock::shade): accumulates the
   // emitted radiance, pushes the node when it scatters, retires finished samples.
-  RT_DEV void shade(const Scene &s, const RenderParams &p, WaveShared &sh, const Hit &h) {
+  RT_DEV void shade(const Scene &s, const RenderParams &p, WaveShared &sh, const Hit &h, const ShadeFetch *fetch = nullptr) {
     const int lane = threadIdx.x & 63;
     bool push = false;
     V3 vec = mk3(0.f, 0.f, 0.f), weight = vec;
@@ -222,8 +222,13 @@ template <bool FAST> struct WavePath {
       if (h.object < 0) {
         emitted = mk3(p.background[0], p.background[1], p.background[2]);
       } else {
-        const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + h.shape);
-        const float4 r0 = rec[0], r1 = rec[1];
+        float4 r0, r1;
+        if (fetch && fetch->have) { // the shading record came with the winner's matrices (rt_bvh.h)
+          r0 = fetch->r0, r1 = fetch->r1;
+        } else {
+          const float4 *rec = reinterpret_cast<const float4 *>(s.shape_shade + h.shape);
+          r0 = rec[0], r1 = rec[1];
+        }
         const uint32_t mflags = __float_as_uint(r0.w);
         V3 reflected = mk3(r0.x, r0.y, r0.z);
         emitted = mk3(r1.x, r1.y, r1.z);
