@@ -1004,6 +1004,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       block = 64u * static_cast<unsigned>(waves);
       path_kernel = iso ? rt_wide_kernel_iso(k, waves) : rt_wide_kernel_gen(k, waves);
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_wide<%s,K=%d,W=%d>", iso ? "ISO" : "GEN", k, waves);
+      nodes_per_level = 64, stacks_per_block = waves, node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave (rt_wavepath.h)
       if (iso && !(cfg->flags & RT_FLAG_VALU_ONLY)) {
         // The filter on the matrix cores (rt_tile.h): 8 tiles of 32 spheres per wave and pass.  Waves per workgroup, measured
         // (Mrays/s at W = 1 / 2 / 4 / 8; N=512: 10723 / 10261 / 9839 / 8894; N=1024: 5366 / 5446 / 5585 / 5207; N=4096: 1275 /

@@ -1,6 +1,6 @@
 // rt_wide.h — the path kernel for large worlds: spheres in registers, rays through an LDS queue.
 #pragma once
-#include "rt_path.h"
+#include "rt_wavepath.h"
 
 namespace rtd {
 
@@ -221,8 +221,10 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
   constexpr int WIDE_THREADS = 64 * W;
   __shared__ WideRayT<ISO> q_ray[WIDE_THREADS];
   __shared__ unsigned long long q_key[WIDE_THREADS];
-  __shared__ int q_count;
-  __shared__ PathShared<WIDE_THREADS> sh;
+  __shared__ int q_cnt[W], q_live[W]; // per wave: rays queued this iteration, pool not yet dry
+  // One wave-run pool per wave (rt_wavepath.h); the waves share the ray queue — each queues into its own 64 slots — and the
+  // sphere rows, and meet twice per iteration, around the scan (see rt_tile.h, which has the same structure).
+  __shared__ WaveShared sh_all[W];
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // The spheres of s.wide_recs / s.wide_iso are held in registers as n_rows rows of 64 (the last one may be partly
@@ -230,8 +232,9 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
   // of a pass belongs to wave r % W, register row r / W; rows past n_rows are never-hit dummies.
   const int n_rows = s.wide_rows;
   const int n_pass = (n_rows + K * WIDE_WAVES - 1) / (K * WIDE_WAVES);
-  PathBlock<WIDE_THREADS, true> L;
-  L.init(p, sh);
+  WaveShared &sh = sh_all[wave];
+  WavePath<true> L;
+  L.init(p, sh, (int)blockIdx.x * W + wave);
   WideSlots<ISO, K> slots;
 
 #ifdef RT_PROFILE_PHASES
@@ -242,20 +245,14 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
 #endif
   for (;;) {
     RT_STAMP(ts0);
-    // -- every lane gets a ray from the workgroup's node pool; the live rays are queued (compacted) ----
-    if (threadIdx.x == 0)
-      q_count = 0;
-    if (!L.deal(s, p, sh)) // synchronises the workgroup
-      break;
+    // -- every lane gets a ray from its wave's node pool; the live rays are queued in the wave's slots ----
+    const bool wave_live = L.deal(s, p, sh);
+    const unsigned long long live = __ballot(L.active);
+    if (lane == 0)
+      q_cnt[wave] = __popcll(live), q_live[wave] = wave_live ? 1 : 0;
     int my_q = -1;
     if (L.active) {
-      const unsigned long long live = __ballot(1);
-      const int rank = __popcll(live & ((1ull << lane) - 1ull));
-      int base = 0;
-      if (rank == 0)
-        base = atomicAdd(&q_count, __popcll(live));
-      base = __shfl(base, __ffsll((long long)live) - 1, 64);
-      my_q = base + rank;
+      my_q = 64 * wave + __popcll(live & ((1ull << lane) - 1ull));
       int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
 #ifdef RT_NO_SELF_EXACT
       self = -1;
@@ -265,7 +262,14 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
       q_key[my_q] = ~0ull;
     }
     __syncthreads();
-    const int n_q = q_count;
+    int n_q = 0, any_live = 0; // uniform
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      n_q += __builtin_amdgcn_readfirstlane(q_cnt[w]);
+      any_live |= __builtin_amdgcn_readfirstlane(q_live[w]);
+    }
+    if (!any_live) // a wave whose pool has run dry keeps coming along (its spheres are part of every ray's scan) until all have
+      break;
     RT_STAMP(ts1);
 
     // -- every lane is K spheres: all waves test every queued ray ----------------------------------
@@ -281,16 +285,21 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
       // the lanes test the current one.
       // (a third register set, two rays in flight, was measured and lost: N=512 7.11 -> 6.71 Grays/s — the registers cost more
       // in spills than the deeper prefetch hides)
-      WideRayT<ISO> ra = q_ray[0];
-      int qi = 0;
-      for (; qi + 1 < n_q; qi += 2) {
-        const WideRayT<ISO> rb = q_ray[qi + 1];
-        test_ray(ra, qi);
-        ra = q_ray[min(qi + 2, n_q - 1)];
-        test_ray(rb, qi + 1);
+      for (int w = 0; w < W; ++w) { // the slots of wave w
+        const int q0 = 64 * w, q_end = q0 + __builtin_amdgcn_readfirstlane(q_cnt[w]);
+        if (q_end == q0)
+          continue;
+        WideRayT<ISO> ra = q_ray[q0];
+        int qi = q0;
+        for (; qi + 1 < q_end; qi += 2) {
+          const WideRayT<ISO> rb = q_ray[qi + 1];
+          test_ray(ra, qi);
+          ra = q_ray[min(qi + 2, q_end - 1)];
+          test_ray(rb, qi + 1);
+        }
+        if (qi < q_end)
+          test_ray(ra, qi);
       }
-      if (qi < n_q)
-        test_ray(ra, qi);
     }
     __syncthreads();
     RT_STAMP(ts2);
@@ -325,7 +334,7 @@ __global__ void __launch_bounds__(64 * W, RT_WIDE_OCC) k_render_path_wide(Scene 
       }
       h = world_finish_hit<true, true>(s, L.ray, best);
     }
-    L.shade(s, p, sh, h); // ends with a workgroup barrier: q_count / q_ray are rewritten at the top
+    L.shade(s, p, sh, h); // the wave's own pool: no barrier; a wave's queue slots are rewritten by itself only
 #ifdef RT_PROFILE_PHASES
     RT_STAMP(ts3);
     t_queue += ts1 - ts0, t_scan += ts2 - ts1, t_shade += ts3 - ts2, n_iter += 1, n_rays_q += n_q;
