@@ -931,7 +931,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const bool use_wide = !exact && !use_bvh && sc->dev.n_wide >= wide_min; // measured: see RT_WIDE_MIN_SPHERES
     // Small worlds with small lookup tables (every sample scene of the reference): the pool run wave by wave (rt_wavepath.h)
     const bool use_wave = small_tables && !use_bvh && !use_wide;
-    int nodes_per_level = 0, stacks_per_block = 1, node_words = rtd::NODE_WORDS; // nodes_per_level 0: the block size, set below
+    int nodes_per_level = 64, stacks_per_block = 1, node_words = rtd::WAVE_NODE_WORDS; // every path kernel: one pool of 64 lanes per wave
     if (use_wave) {
       // Worlds without CSG objects run the variant compiled without the evaluators and their tables (102 VGPRs at 4 waves per
       // SIMD, 94 at 5, 80 at 6 with 2 spilled; 25 KB of LDS, so 6 workgroups fit a CU): measured on C3, waves per SIMD
@@ -959,6 +959,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       path_kernel = exact ? reinterpret_cast<const void *>(rtd::k_render_path<false>) : reinterpret_cast<const void *>(rtd::k_render_path<true>);
       std::snprintf(kernel_name, sizeof kernel_name, "k_render_path<%s>", exact ? "EXACT" : "FMA");
       block = rtd::PATH_THREADS;
+      nodes_per_level = 64, stacks_per_block = rtd::PATH_THREADS / 64, node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave
     }
     if (use_bvh) {
       // The tree (or its top) and, if they fit too, the leaf spheres go to LDS next to the workgroup's pool state:
@@ -1028,9 +1029,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     per_cu = std::max(per_cu, 1);
     const uint64_t want = (p.n_samples + block - 1) / block;
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
-    // node stack of each workgroup: at most `block` nodes per depth level (rt_path.h)
-    if (nodes_per_level == 0)
-      nodes_per_level = static_cast<int>(block);
+    // one node stack per wave: at most 64 nodes per depth level (rt_path.h: the stack discipline)
+    stacks_per_block = static_cast<int>(block / 64);
     p.pool_cap = nodes_per_level * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
     const size_t stack_bytes = static_cast<size_t>(stacks_per_block) * node_words * static_cast<size_t>(p.pool_cap) * sizeof(float); // per workgroup
     if (ws.fixed) {

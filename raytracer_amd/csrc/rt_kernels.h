@@ -5,7 +5,7 @@
 //  k_resolve              box filter: sum of a pixel's spp^2 samples in the reference's order, * 1/spp^2
 //  k_trace_rays / k_offset_if_visible / k_aa_jitter   batch parity entry points
 #pragma once
-#include "rt_path.h"
+#include "rt_wavepath.h"
 
 namespace rtd {
 
@@ -86,60 +86,16 @@ template <int MODE> __global__ void __launch_bounds__(256) k_render_simple(Scene
   wave_add_tally(p.counters, 1, capped);
 }
 
-// Path kernel for small worlds: the workgroup's node pool deals one ray per lane (rt_path.h), every lane
-// scans the (few) objects itself with wave-uniform scalar record loads.  The kernel waits on memory more than it
-// computes (PMC: 60 % of wave cycles parked), so it is built for 5 waves per SIMD (96 VGPRs, 60-110 bytes of spills per lane):
-// measured 4 -> 5 waves: C4 147 -> 130 ms, C3 24.2 -> 22.2 ms; 6 and 8 waves spill too much.
+// The plain path kernel: one ray per lane from the wave's node pool (rt_wavepath.h), every lane scans the objects itself with
+// wave-uniform scalar record loads.  It serves RT_FLAG_EXACT_ARITHMETIC (FAST = false: the reference's unfused operation
+// order — the kernel the parity tests compare with the oracle) and worlds whose lookup tables exceed what k_render_path_wave
+// stages in LDS.
 constexpr int PATH_THREADS = 256;
-// TABLES_LDS (FAST only, small worlds — the limits below, checked by the host): every table the kernel looks things up
-// in behind a hit — per shape the composed transforms, kind and shading record; materials; pigments (not texels); the
-// CSG leaf / chain / program tables — is staged in LDS, and the Scene copy the workgroup uses points there.  The chains
-// of dependent trips to L2 (hit record -> shading record -> material -> pigment; CSG leaf -> chain -> program -> shape)
-// become LDS reads.
-template <typename T> RT_DEV void stage_table(const T *&table, T *lds, int n) {
-  for (int i = threadIdx.x; i < n; i += PATH_THREADS)
-    lds[i] = table[i];
-  table = lds;
-}
-template <bool FAST, bool TABLES_LDS = false> __global__ void __launch_bounds__(PATH_THREADS, 5) k_render_path(Scene s, RenderParams p) {
-  __shared__ PathShared<PATH_THREADS> sh;
-  using L = PathLdsLimits;
-  constexpr int ON = TABLES_LDS ? 1 : 0;
-  __shared__ float lds_w2l[ON * 12 * L::SHAPES + 1], lds_l2w[ON * 12 * L::SHAPES + 1];
-  __shared__ ShadeRec lds_shade[ON * L::SHAPES + 1];
-  __shared__ uint8_t lds_kind[ON * L::SHAPES + 1];
-  __shared__ uint32_t lds_mat_brdf_pig[ON * L::MATERIALS + 1], lds_mat_emit_pig[ON * L::MATERIALS + 1];
-  __shared__ uint8_t lds_mat_needs_uv[ON * L::MATERIALS + 1], lds_pig_kind[ON * L::PIGMENTS + 1];
-  __shared__ float lds_pig_c1[ON * 3 * L::PIGMENTS + 1], lds_pig_c2[ON * 3 * L::PIGMENTS + 1];
-  __shared__ int32_t lds_pig_n[ON * L::PIGMENTS + 1];
-  __shared__ CsgLeaf lds_csg_leaf[ON * L::CSG_LEAVES + 1];
-  __shared__ CsgStep lds_csg_path[ON * L::CSG_PATH + 1];
-  __shared__ int32_t lds_csg_range[ON * 4 * L::CSG_NODES + 1];
-  __shared__ uint8_t lds_csg_op[ON * L::CSG_NODES + 1];
-  __shared__ CsgProgEntry lds_csg_prog[ON * L::CSG_PROG + 1];
-  __shared__ CsgTop lds_csg_tops[ON * L::CSG_TOPS + 1];
-  if (TABLES_LDS) {
-    const int ns = p.tab_shapes, nm = p.tab_materials, np = p.tab_pigments;
-    stage_table(s.shape_w2l, lds_w2l, 12 * ns);
-    stage_table(s.shape_l2w, lds_l2w, 12 * ns);
-    stage_table(s.shape_shade, lds_shade, ns);
-    stage_table(s.shape_kind, lds_kind, ns);
-    stage_table(s.material_brdf_pigment, lds_mat_brdf_pig, nm);
-    stage_table(s.material_emission_pigment, lds_mat_emit_pig, nm);
-    stage_table(s.material_needs_uv, lds_mat_needs_uv, nm);
-    stage_table(s.pigment_kind, lds_pig_kind, np);
-    stage_table(s.pigment_color1, lds_pig_c1, 3 * np);
-    stage_table(s.pigment_color2, lds_pig_c2, 3 * np);
-    stage_table(s.pigment_n_intervals, lds_pig_n, np);
-    stage_table(s.csg_leaf, lds_csg_leaf, p.tab_csg_leaves);
-    stage_table(s.csg_path, lds_csg_path, p.tab_csg_path);
-    stage_table(s.csg_prog_range, lds_csg_range, 4 * p.tab_csg_nodes);
-    stage_table(s.csg_op, lds_csg_op, p.tab_csg_nodes);
-    stage_table(s.csg_prog, lds_csg_prog, p.tab_csg_prog);
-    stage_table(s.csg_tops, lds_csg_tops, s.n_csg_tops);
-  }
-  PathBlock<PATH_THREADS, FAST> B;
-  B.init(p, sh); // synchronises the workgroup
+template <bool FAST> __global__ void __launch_bounds__(PATH_THREADS, 5) k_render_path(Scene s, RenderParams p) {
+  __shared__ WaveShared sh_all[PATH_THREADS / 64]; // one wave-run pool per wave (rt_wavepath.h): the waves of a workgroup never meet
+  WaveShared &sh = sh_all[threadIdx.x >> 6];
+  WavePath<FAST> B;
+  B.init(p, sh, (int)blockIdx.x * (PATH_THREADS / 64) + (int)(threadIdx.x >> 6));
   while (B.deal(s, p, sh)) {
     Hit h;
     h.object = h.shape = -1;

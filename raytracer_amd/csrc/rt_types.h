@@ -154,8 +154,7 @@ struct RenderParams {
   uint64_t sample_stride;      // path mode: coprime to n_samples, about 0.618 n_samples (see rt_path.h)
   float *samples_out;          // [n_samples][3] (== framebuffer when spp_edge == 1)
   unsigned long long *counters; // [0] next sample; rays and capped samples: spread over slots from COUNTER_BASE (rt_path.h)
-  // path mode: one node stack per workgroup in HBM, SoA: word w of node i of block b at
-  // pool[(b * NODE_WORDS + w) * pool_cap + i]   (rt_path.h)
+  // path mode: one node stack per WAVE in HBM, 64-byte records: node i of wave v at pool[(v * pool_cap + i) * 16 ...]  (rt_wavepath.h)
   float *pool;
   int32_t pool_cap;
   // RT_FLAG_ACCEL_BVH: heap slots and leaf spheres staged in LDS; whether leaves use the (centre, r^2) form (rt_bvh.h)
