@@ -211,11 +211,11 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
     RT_TSTAMP(ts2);
 
     // -- every lane is a ray again: finish the query, shade, produce the next ray -------------------
-    // (Phase split per iteration of a one-wave workgroup at N=512, -DRT_PROFILE_PHASES: deal + queue 11.2 k cycles, filter
-    // 33.3 k, this finish 11.2 k, shade 6.2 k; at N=4096, W=4: 19 k / 333 k / 15 k / 15 k.  The finish is a chain of dependent
-    // trips to memory: position -> ids -> matrices -> shading record.  Fetching the winner's matrices and shading record by
-    // position in one trip was built and measured: the 36-52 registers it holds push the phase into scratch — 74-114 spilled
-    // registers, finish 11.2 k -> 15.4 k cycles, frame 9960 -> 9416 Mrays/s — and was not kept.)
+    // (Phase split per iteration of a wave at N=512, -DRT_PROFILE_PHASES: deal + queue 5.6 k cycles, filter 35.9 k, this
+    // finish 10.7 k, shade 5.6 k; at N=4096, W=4: 13 k / 308 k / 14 k / 9 k.  The finish is a chain of dependent trips to
+    // memory: position -> ids -> matrices -> shading record.  Fetching the winner's matrices and shading record by position
+    // in one trip was built and measured twice — the registers it holds cost more than the trips: 10 765 -> 10 400 Mrays/s —
+    // and was not kept.)
     Hit h;
     h.object = h.shape = -1;
     h.t = 0.f;
