@@ -30,6 +30,8 @@ namespace rtd {
 // a3 = cz | k), prepared by the host (Scene::wide_tiles).  S = 8 tiles per wave and pass (256 spheres in 24 registers; bigger
 // worlds take several passes, the registers reloaded from L2 per pass).  Measured, N=512, W=1: S=4 9822, S=8 9926, S=16 8900
 // Mrays/s (at 16 the lane state that shading needs is spilled around the scan); 5 waves per SIMD (96 VGPRs): 8950.
+// With the per-wave pools: S=4 / 8 / 16 10 451 / 10 635 / 10 583; 5 waves per SIMD 10 754 against 10 710 at 4 (31 spilled
+// registers: within noise, not taken).
 //
 // What it buys (N=512 1080p AA=4 / a 1/16 slice of the N=4096 frame): 7.60 -> 9.94 and 1.02 -> 1.46 Grays/s over the VALU filter of
 // rt_wide.h.  The binary32 MFMA and the VALU share the SIMD's fp32 lanes (scripts/microbench/mfma_probe.hip: 4 MFMAs alone
