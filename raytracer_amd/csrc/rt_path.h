@@ -97,6 +97,14 @@ RT_DEV uint64_t node_root_key(uint64_t seq_number, uint64_t global_sample) {
   return mix64(global_sample ^ mix64(seq_number));
 }
 RT_DEV long long to_fixed(float x) { return to_fixed32(x); }
+// |to_fixed32(x)| in five instructions: v_fract_f32 gives |x| - floor(|x|) exactly (the same value as ax - (float)hi in
+// to_fixed32), so the two words are the same bits.
+RT_DEV unsigned long long to_fixed_abs(float x) {
+  const float ax = fminf(fabsf(x), 2147483520.f);
+  const uint32_t hi = (uint32_t)ax;
+  const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(ax) * 4294967296.f);
+  return ((unsigned long long)hi << 32) | lo;
+}
 RT_DEV float from_fixed(unsigned long long a) { return (float)((double)(long long)a * (1.0 / 4294967296.0)); }
 
 

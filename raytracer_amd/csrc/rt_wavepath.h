@@ -27,10 +27,10 @@ namespace rtd {
 constexpr int WAVE_NODE_WORDS = 16; // point(3) depth-and-slot(1) | vec(3) children-left(1) | weight(3) shape-hit(1) | key(2) pad(2)
 
 struct WaveShared {              // LDS state of one wave: 3712 bytes
-  unsigned long long acc[64][3]; // per sample slot: fixed-point radiance
+  unsigned long long acc[3][64]; // per colour channel and sample slot: fixed-point radiance (slots 8 bytes apart: two slots never share a bank pair)
   unsigned long long slot_g[64]; // per sample slot: sample index of this call
   int pending[64];               // per sample slot: rays not yet shaded (-1: slot free)
-  int mark[64];                  // dealing: position c holds (owner lane + 1) if a node's run of children starts at c
+  int mark[64];                  // dealing: position c is nonzero if a node's run of children starts at c
   short free_list[64];
   unsigned short rem[8 * 64];    // children left per stack node, when the stack holds at most 512 nodes (else node word 7)
 };
@@ -39,7 +39,7 @@ struct WaveShared {              // LDS state of one wave: 3712 bytes
 template <int CTRL, int ROW_MASK, int BANK_MASK> RT_DEV int dpp_or_zero(int x) {
   return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, false); // lanes without a source get 0
 }
-// Inclusive prefix sum / prefix maximum over the 64 lanes of the wave, all lanes active (values >= 0 for the maximum).
+// Inclusive prefix sum over the 64 lanes of the wave, all lanes active.
 RT_DEV int wave_scan_add(int x) {
   int r = x;
   r += dpp_or_zero<0x111, 0xf, 0xf>(x);
@@ -49,17 +49,6 @@ RT_DEV int wave_scan_add(int x) {
   r += dpp_or_zero<0x118, 0xf, 0xc>(r);
   r += dpp_or_zero<0x142, 0xa, 0xf>(r);
   r += dpp_or_zero<0x143, 0xc, 0xf>(r);
-  return r;
-}
-RT_DEV int wave_scan_max(int x) {
-  int r = x;
-  r = max(r, dpp_or_zero<0x111, 0xf, 0xf>(x));
-  r = max(r, dpp_or_zero<0x112, 0xf, 0xf>(x));
-  r = max(r, dpp_or_zero<0x113, 0xf, 0xf>(x));
-  r = max(r, dpp_or_zero<0x114, 0xf, 0xe>(r));
-  r = max(r, dpp_or_zero<0x118, 0xf, 0xc>(r));
-  r = max(r, dpp_or_zero<0x142, 0xa, 0xf>(r));
-  r = max(r, dpp_or_zero<0x143, 0xc, 0xf>(r));
   return r;
 }
 // Orders this wave's LDS / global accesses as written (other lanes of the wave read what a lane wrote): the hardware
@@ -80,6 +69,7 @@ template <bool FAST> struct WavePath {
   V3 throughput;
   int depth, slot;
   int origin_shape; // the shape this ray leaves (-1: a camera ray); read by the large-world kernel (rt_tile.h) only
+  int run; // first lane | (one past the last lane) << 8 of this lane's RUN: the lanes dealt children of the same node (a fresh sample: itself)
   uint32_t rays;
   // wave state (uniform: scalar registers)
   int top, n_free, res_count, exhausted;
@@ -98,6 +88,7 @@ template <bool FAST> struct WavePath {
     throughput = mk3(1.f, 1.f, 1.f);
     depth = slot = 0;
     origin_shape = -1;
+    run = 0;
     rays = 0;
     top = 0, n_free = 64, res_count = 0, exhausted = 0, res_base = 0;
     cap = p.pool_cap;
@@ -159,7 +150,10 @@ template <bool FAST> struct WavePath {
     wave_sync();
     active = false;
     // owner of position `lane`: the last run start at or before it
-    const int owner = wave_scan_max(sh.mark[lane]) - 1;
+    // every node on the stack has children left, so the runs start at the marked positions in lane order: the owner of
+    // position c is the (number of marks at or before c)-th node lane
+    const unsigned long long starts = __ballot(sh.mark[lane] != 0);
+    const int owner = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u)) + (int)((starts >> lane) & 1ull) - 1;
     const int src = max(owner, 0);
     const int owner_lo = __shfl(lo, src, 64), owner_rem = __shfl(rem, src, 64);
     if (lane < take) {
@@ -176,6 +170,7 @@ template <bool FAST> struct WavePath {
       const V3 vec = mk3(b.x, b.y, b.z);
       throughput = mk3(c.x, c.y, c.z);
       origin_shape = __float_as_int(c.w);
+      run = owner_lo | (min(owner_lo + owner_rem, 64) << 8);
       if (meta >> 31) { // SpecularBRDF: every child is the mirror ray, no draw
         ray.d = vec;
         ray.tmin = 1.e-5f;
@@ -190,9 +185,9 @@ template <bool FAST> struct WavePath {
       // the q-th sample taken from the queue is sample (q * stride) mod n (see PathBlock::deal)
       const uint64_t g = ((new_base + (uint64_t)j) * p.sample_stride) % p.n_samples;
       slot = sh.free_list[n_free - 1 - j];
-      sh.acc[slot][0] = 0ull;
-      sh.acc[slot][1] = 0ull;
-      sh.acc[slot][2] = 0ull;
+      sh.acc[0][slot] = 0ull;
+      sh.acc[1][slot] = 0ull;
+      sh.acc[2][slot] = 0ull;
       sh.slot_g[slot] = g;
       sh.pending[slot] = 1;
       const SampleId sid = decode_sample(p, g);
@@ -201,6 +196,7 @@ template <bool FAST> struct WavePath {
       depth = 0;
       origin_shape = -1;
       throughput = mk3(1.f, 1.f, 1.f);
+      run = lane | ((lane + 1) << 8);
       active = true;
     }
     top -= n_pop;
@@ -216,6 +212,7 @@ template <bool FAST> struct WavePath {
     bool push = false;
     V3 vec = mk3(0.f, 0.f, 0.f), weight = vec;
     int brdf = 0;
+    V3 c = vec; // this ray's contribution to its sample: throughput * emitted radiance
     if (active) {
       ++rays;
       V3 emitted;
@@ -243,7 +240,10 @@ template <bool FAST> struct WavePath {
         }
         const float hit_lum = fmaxf(fmaxf(reflected.x, reflected.y), reflected.z);
         push = hit_lum > 0.f;
-        if (depth > p.roulette) {
+        // At depth == max_depth nothing is pushed whatever the roulette says, and the rescaled colour and the generator
+        // are used by children only: the draw is skipped (most rays are at the deepest level, and the stack order brings
+        // them to a wave together, so the whole wave skips it).
+        if (depth > p.roulette && depth < p.max_depth) {
           const float q = fmaxf(1.f - hit_lum, 0.05f);
           if (pcg_random_float(pcg) > q)
             reflected = scale3(reflected, FAST ? __builtin_amdgcn_rcpf(1.f - q) : 1.f / (1.f - q));
@@ -260,19 +260,51 @@ template <bool FAST> struct WavePath {
           weight = mul3(scale3(throughput, 1.f / (float)p.n_rays), reflected);
         }
       }
-      const V3 c = mul3(throughput, emitted);
+      c = mul3(throughput, emitted);
+    }
+    // An LDS atomic costs about one cycle per active lane, and the lanes of a run hit the same address: a 64-lane ds_add_u64
+    // was ~50 LDS cycles, three of them plus the pending counter a fifth of the small-world kernels' time.  So each run adds
+    // ONCE.  pending: the run's first lane adds n_rays x (pushers of the run) - (lanes of the run).  Radiance: the lanes of a
+    // run share their throughput, and rays that reach the same uniform emitter (the sky) then contribute the very same
+    // number: the first contributing lane of the run (its leader) adds  count x value  for all lanes whose contribution
+    // equals its own, bit for bit; a lane with another value adds for itself.  Integer sums: the same total, whoever adds.
+    const unsigned long long pushers = __ballot(push);
+    if (p.n_rays <= 31) { // a run fits a 32-bit mask (uniform branch)
+      const int run_lo = run & 0xff, run_len = (run >> 8) - run_lo;
+      const uint32_t len_mask = (1u << run_len) - 1u;
+      const bool nz = active && (c.x != 0.f || c.y != 0.f || c.z != 0.f);
+      const uint32_t contributors = (uint32_t)(__ballot(nz) >> run_lo) & len_mask; // bit k: lane run_lo + k contributes
+      const int leader = contributors ? run_lo + __builtin_ctz(contributors) : lane;
+      const float lx = __shfl(c.x, leader, 64), ly = __shfl(c.y, leader, 64), lz = __shfl(c.z, leader, 64);
+      const bool same = nz && c.x == lx && c.y == ly && c.z == lz;
+      const uint32_t same_mask = (uint32_t)(__ballot(same) >> run_lo) & len_mask;
+      if (active && lane == run_lo) {
+        const int delta = p.n_rays * __popc((uint32_t)(pushers >> run_lo) & len_mask) - run_len;
+        if (delta != 0)
+          atomicAdd(&sh.pending[slot], delta);
+      }
+      if (nz && (lane == leader || !same)) {
+        const unsigned long long count = lane == leader ? (unsigned long long)__popc(same_mask) : 1ull;
+        unsigned long long fx = to_fixed_abs(c.x), fy = to_fixed_abs(c.y), fz = to_fixed_abs(c.z);
+        if (__ballot(fminf(fminf(c.x, c.y), c.z) < 0.f)) { // negative radiance: in no scene of the reference; a uniform branch
+          fx = c.x < 0.f ? 0ull - fx : fx, fy = c.y < 0.f ? 0ull - fy : fy, fz = c.z < 0.f ? 0ull - fz : fz;
+        }
+        atomicAdd(&sh.acc[0][slot], fx * count);
+        atomicAdd(&sh.acc[1][slot], fy * count);
+        atomicAdd(&sh.acc[2][slot], fz * count);
+      }
+    } else if (active) { // long runs: every lane adds for itself
       if (c.x != 0.f)
-        atomicAdd(&sh.acc[slot][0], (unsigned long long)to_fixed(c.x));
+        atomicAdd(&sh.acc[0][slot], (unsigned long long)to_fixed(c.x));
       if (c.y != 0.f)
-        atomicAdd(&sh.acc[slot][1], (unsigned long long)to_fixed(c.y));
+        atomicAdd(&sh.acc[1][slot], (unsigned long long)to_fixed(c.y));
       if (c.z != 0.f)
-        atomicAdd(&sh.acc[slot][2], (unsigned long long)to_fixed(c.z));
+        atomicAdd(&sh.acc[2][slot], (unsigned long long)to_fixed(c.z));
       const int delta = (push ? p.n_rays : 0) - 1;
       if (delta != 0)
         atomicAdd(&sh.pending[slot], delta);
     }
     // push in reverse lane order (the lane that took the topmost child pushes topmost: see rt_path.h on the stack bound)
-    const unsigned long long pushers = __ballot(push);
     const int n_push = __popcll(pushers);
     if (push) {
       const int below = __popcll(pushers & ((1ull << lane) - 1ull));
@@ -292,9 +324,9 @@ template <bool FAST> struct WavePath {
     const unsigned long long retiring = __ballot(done);
     if (done) {
       float *out = p.samples_out + 3 * sh.slot_g[lane];
-      out[0] = from_fixed(sh.acc[lane][0]);
-      out[1] = from_fixed(sh.acc[lane][1]);
-      out[2] = from_fixed(sh.acc[lane][2]);
+      out[0] = from_fixed(sh.acc[0][lane]);
+      out[1] = from_fixed(sh.acc[1][lane]);
+      out[2] = from_fixed(sh.acc[2][lane]);
       sh.pending[lane] = -1;
       sh.free_list[n_free + __popcll(retiring & ((1ull << lane) - 1ull))] = (short)lane;
     }

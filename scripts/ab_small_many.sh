@@ -6,5 +6,5 @@ for name in product "$@"; do
 import json,sys
 for l in sys.stdin:
     j=json.loads(l)
-    if j['mode']=='path': print('$name', j['config'], round(j['frame_ms'],2), j['rays'])" || exit 1
+    if j['mode']=='path': print('$name', j['config'], round(j['frame_ms'],2), j['rays'], j.get('frame_sha256'))" || exit 1
 done

@@ -5,6 +5,7 @@ and, optionally, synthetic scenes, on one GPU.  Prints one JSON object per line.
     python scripts/run_configs.py [--synth N WIDTH HEIGHT AA]...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,7 +40,8 @@ def run(label, scene, mode, w, h, aa, reps=3):
     print(json.dumps({"config": label, "mode": mode.mode, "size": f"{w}x{h} AA={aa}", "objects": scene.count("n_objects"),
                       "rays": int(st.rays), "samples": int(st.samples), "capped_samples": int(st.capped_samples),
                       "frame_ms": best * 1e3, "Mrays_per_s": st.rays / best / 1e6,
-                      "mean_radiance": float(out.mean())}), flush=True)
+                      "mean_radiance": float(out.mean()),
+                      "frame_sha256": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}), flush=True)
 
 
 def main():
