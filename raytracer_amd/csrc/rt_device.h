@@ -544,10 +544,14 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
         const bool better = t < INF_F && (!found || (first_of_leaf ? (t <= best_t) : (t < best_t))); // ties between leaves go to the later leaf
         if (better) {
           uint32_t mask = 0;
+          // t_in < t < t_out  <=>  t_in - t and t - t_out are both negative: the AND of their sign bits.  Subtractions, shifts
+          // and logic ops issue at 2.3 cycles per wave64 on gfx950, compares and selects at 4.2 (issue_bench.hip).  Equal values
+          // give +0 (not inside, as the strict compares say); an infinite bound gives an infinity of the right sign.
 #pragma unroll
           for (int i = 0; i < LMAX; ++i)
-            mask |= (t > t_in[i] && t < t_out[i]) ? (1u << i) : 0u;
-          if ((table >> mask) & 1ull) {
+            if (i != j) // a leaf's own bit is 0: t is one of its two bounds
+              mask |= ((__float_as_uint(t_in[i] - t) & __float_as_uint(t - t_out[i])) >> (31 - i)) & (1u << i);
+          if (LMAX <= 5 ? (((uint32_t)table >> mask) & 1u) != 0u : ((table >> mask) & 1ull) != 0ull) {
             found = true;
             best_t = t;
             best_leaf = j;
@@ -676,6 +680,70 @@ template <bool FAST> RT_DEV void scan_spheres(const ScanRec *recs, int n, const 
     sphere_scan_test<FAST>(a, ray, best, skip_shape);
 }
 
+// The same scan for the small-world kernels whose shape tables are staged in LDS (rt_wavepath.h): the inverse matrix comes
+// from the LDS table into VECTOR registers (three broadcast ds_read_b128) instead of scalar registers.  On gfx950 a v_fma_f32 /
+// v_mul_f32 with a scalar-register operand issues at 4.2 cycles per wave64, with vector operands only at 2.3
+// (scripts/microbench/issue_bench.hip): the 21 matrix multiply-adds of a test were a third slower than they need be.
+// Only the two indices of a record are read through the scalar cache.  Same arithmetic, same order: same bits.
+typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+struct TabRec { // one scan record of the small-world kernels: matrix in vector registers, indices in scalar registers
+  float4 m0, m1, m2; // m[0..3] m[4..7] m[8..11]
+  int object, shape;
+};
+RT_DEV TabRec load_tab_rec(const Scene &s, const ScanRec *recs, int i) {
+  ConstI32 ids = (ConstI32)(uintptr_t)&recs[i].object; // {object, shape}: one s_load_dwordx2
+  TabRec r;
+  r.object = ids[0], r.shape = ids[1];
+  const float4 *mp = reinterpret_cast<const float4 *>(s.shape_w2l + 12 * r.shape);
+  r.m0 = mp[0], r.m1 = mp[1], r.m2 = mp[2];
+  return r;
+}
+RT_DEV void sphere_tab_test(const TabRec &r, const Ray &ray, Best &best) {
+  const float4 m0 = r.m0, m1 = r.m1, m2 = r.m2;
+  const float dx = fmaf(m0.x, ray.d.x, fmaf(m0.y, ray.d.y, m0.z * ray.d.z));
+  const float dy = fmaf(m0.w, ray.d.x, fmaf(m1.x, ray.d.y, m1.y * ray.d.z));
+  const float dz = fmaf(m1.z, ray.d.x, fmaf(m1.w, ray.d.y, m2.x * ray.d.z));
+  const float ox = fmaf(m0.x, ray.o.x, fmaf(m0.y, ray.o.y, fmaf(m0.z, ray.o.z, m2.y)));
+  const float oy = fmaf(m0.w, ray.o.x, fmaf(m1.x, ray.o.y, fmaf(m1.y, ray.o.z, m2.z)));
+  const float oz = fmaf(m1.z, ray.o.x, fmaf(m1.w, ray.o.y, fmaf(m2.x, ray.o.z, m2.w)));
+  const float a = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+  const float b = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
+  const float c = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
+  const float disc = fmaf(b, b, -(a * c));
+  if (disc > 0.f) {
+    const float sq = __builtin_amdgcn_sqrtf(disc);
+    const float inv_a = __builtin_amdgcn_rcpf(a);
+    const float t1 = (-b - sq) * inv_a;
+    const float t2 = (-b + sq) * inv_a;
+    float t = t1;
+    bool ok = true;
+    if (t1 < ray.tmin) {
+      t = t2;
+      ok = t2 > ray.tmin && t2 < ray.tmax;
+    }
+    if (ok && t < best.t) {
+      best.t = t;
+      best.object = r.object;
+      best.shape = r.shape;
+    }
+  }
+}
+RT_DEV void scan_spheres_tab(const Scene &s, const Ray &ray, Best &best) {
+  const int n = s.n_spheres;
+  if (n <= 0)
+    return;
+  TabRec a = load_tab_rec(s, s.spheres, 0); // the next record's reads are in flight while the lanes test the current one
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    const TabRec b = load_tab_rec(s, s.spheres, i + 1);
+    sphere_tab_test(a, ray, best);
+    a = load_tab_rec(s, s.spheres, min(i + 2, n - 1));
+    sphere_tab_test(b, ray, best);
+  }
+  if (i < n)
+    sphere_tab_test(a, ray, best);
+}
+
 // The sphere a ray LEAVES is the one sphere whose test decides something systematic: a mirror ray (tmin = 1e-5) starts a
 // rounding error away from the surface, and whether it finds the exit root of its own sphere beyond tmin is, in the
 // reference's arithmetic, close to a coin flip for small far spheres (the root cancels ~4 digits: the reference re-hits on
@@ -718,10 +786,26 @@ struct ShadeFetch {
 // a quarter of its register budget: 128 -> 94 VGPRs, one more wave per SIMD).
 // TT4 = true: every tree of the world has a truth table and at most 4 leaves (the host checks): only that evaluator is
 // compiled in (C4: 21 -> 9 spilled registers at 5 waves per SIMD, 43.8 -> 41.6 ms).
-template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = false> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
+// TAB (small-world kernels, tables in LDS): the planes' matrix rows come from the LDS table into vector registers, as in scan_spheres_tab.
+template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = false, bool TAB = false> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
   if (fetch)
     fetch->have = false;
   for (int i = 0; i < s.n_planes; ++i) {
+    if (FAST && TAB) {
+      ConstI32 ids = (ConstI32)(uintptr_t)&s.planes[i].object;
+      const int object = ids[0], shape = ids[1];
+      const float *m = s.shape_w2l + 12 * shape;
+      const float oz = fmaf(m[6], ray.o.x, fmaf(m[7], ray.o.y, fmaf(m[8], ray.o.z, m[11])));
+      const float dz = fmaf(m[6], ray.d.x, fmaf(m[7], ray.d.y, m[8] * ray.d.z));
+      const float t = -oz * __builtin_amdgcn_rcpf(dz);
+      const bool hit = !are_close(dz, 0.f) && !(t < ray.tmin || t > ray.tmax);
+      if (hit && (t < best.t || (t == best.t && object < best.object))) {
+        best.t = t;
+        best.object = object;
+        best.shape = shape;
+      }
+      continue;
+    }
     const RecRegs r = load_rec(s.planes, i);
     float t;
     bool hit;
@@ -792,13 +876,16 @@ template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = fals
 
 // World::ray_intersection — shapes.hpp:547-561.  Closest hit; ties go to the lowest object index
 // (strict `<` in insertion order).
-template <bool FAST, bool CSG = true, bool TT4 = false> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
+template <bool FAST, bool CSG = true, bool TT4 = false, bool TAB = false> RT_DEV Hit world_ray_intersection(const Scene &s, const Ray &ray) {
   Best best;
   best.t = INF_F;
   best.object = 0x7fffffff;
   best.shape = -1;
-  scan_spheres<FAST>(s.spheres, s.n_spheres, ray, best);
-  return world_finish_hit<FAST, false, CSG, TT4>(s, ray, best);
+  if (FAST && TAB)
+    scan_spheres_tab(s, ray, best);
+  else
+    scan_spheres<FAST>(s.spheres, s.n_spheres, ray, best);
+  return world_finish_hit<FAST, false, CSG, TT4, FAST && TAB>(s, ray, best);
 }
 
 // World::on_off_ray_intersection — shapes.hpp:567-578 (only the boolean is used, renderers.hpp:62-69)

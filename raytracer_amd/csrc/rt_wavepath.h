@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_pat
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
     if (B.active)
-      h = world_ray_intersection<FAST, CSG, TT4>(s, B.ray);
+            h = world_ray_intersection<FAST, CSG, TT4, true>(s, B.ray); // TAB: the shape tables are in LDS
     RT_WSTAMP(ts2);
     B.shade(s, p, sh, h);
 #ifdef RT_PROFILE_PHASES
