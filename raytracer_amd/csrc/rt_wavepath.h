@@ -61,7 +61,10 @@ RT_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // (Measured and not kept: taking fresh samples only in batches of 4-32 lanes, so that the camera branch runs less often:
 // C3 15.7 -> 15.5 ms at best, within noise.)
-template <bool FAST> struct WavePath {
+// RUNS: one LDS atomic per run of lanes instead of one per lane (see shade()).  On for the small-world kernel, where the
+// atomics were a fifth of the time; off for the large-world kernels, whose VALU shares its lanes with the matrix
+// instructions of the filter and pays more for the extra ~35 instructions than the atomics cost (N=512: -1.7 % with it).
+template <bool FAST, bool RUNS = false> struct WavePath {
   // lane state of the current iteration
   bool active;
   Ray ray;
@@ -269,7 +272,7 @@ template <bool FAST> struct WavePath {
     // number: the first contributing lane of the run (its leader) adds  count x value  for all lanes whose contribution
     // equals its own, bit for bit; a lane with another value adds for itself.  Integer sums: the same total, whoever adds.
     const unsigned long long pushers = __ballot(push);
-    if (p.n_rays <= 31) { // a run fits a 32-bit mask (uniform branch)
+    if (RUNS && p.n_rays <= 31) { // a run fits a 32-bit mask (uniform branch)
       const int run_lo = run & 0xff, run_len = (run >> 8) - run_lo;
       const uint32_t len_mask = (1u << run_len) - 1u;
       const bool nz = active && (c.x != 0.f || c.y != 0.f || c.z != 0.f);
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(WAVEPATH_THREADS, WAVES_PER_SIMD) k_render_pat
   }
   const int wave = threadIdx.x >> 6;
   WaveShared &sh = reinterpret_cast<WaveShared *>(wave_lds)[wave];
-  WavePath<FAST> B;
+  WavePath<FAST, true> B;
   B.init(p, sh, blockIdx.x * WAVEPATH_WAVES + wave);
   __syncthreads(); // the tables are in place; from here on the waves of the workgroup never meet again
 #ifdef RT_PROFILE_PHASES

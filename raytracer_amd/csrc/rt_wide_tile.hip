@@ -6,16 +6,15 @@
 #ifndef RT_TILE_S
 #define RT_TILE_S 8
 #endif
-#define RT_T(SS, WW) reinterpret_cast<const void *>(rtd::k_render_path_tile<RT_TILE_S, WW>)
+#define RT_T(WW, CSG) reinterpret_cast<const void *>(rtd::k_render_path_tile<RT_TILE_S, WW, CSG>)
 
-// 8 sphere tiles per wave and pass (measured against 4 and 16, see rt_tile.h), `waves` waves per workgroup
+// 8 sphere tiles per wave and pass (measured against 4 and 16, see rt_tile.h), `waves` waves per workgroup; worlds without
+// CSG objects run the variants compiled without the evaluators (fewer registers spilled)
 const void *rt_tile_kernel(int waves, bool csg) {
-  if (waves == 1 && !csg)
-    return reinterpret_cast<const void *>(rtd::k_render_path_tile<RT_TILE_S, 1, false>);
   switch (waves) {
-  case 1: return RT_T(8, 1);
-  case 2: return RT_T(8, 2);
-  case 4: return RT_T(8, 4);
-  default: return RT_T(8, 8);
+  case 1: return csg ? RT_T(1, true) : RT_T(1, false);
+  case 2: return csg ? RT_T(2, true) : RT_T(2, false);
+  case 4: return csg ? RT_T(4, true) : RT_T(4, false);
+  default: return csg ? RT_T(8, true) : RT_T(8, false);
   }
 }
