@@ -451,6 +451,11 @@ static col3 pigment_eval(S *s, uint32_t pg, float u, float v) {
     int row = (int)(v * (float)h);
     if (col >= w) col = w - 1;
     if (row >= h) row = h - 1;
+    /* v = acos(z) / pi is NaN when rounding leaves |z| a hair above 1 (a sphere hit at a pole, ~1 in 10^8): (int)NaN is INT_MIN
+       on x86 and the reference then indexes out of bounds (assert / undefined behaviour, materials.hpp:120-137 clamps only
+       upwards).  Defined here, and in the device code, as index 0. */
+    if (col < 0) col = 0;
+    if (row < 0) row = 0;
     const float *px = s->texels + 3 * ((size_t)s->pigment_tex_offset[pg] + (size_t)row * (size_t)w + (size_t)col);
     c.r = px[0], c.g = px[1], c.b = px[2];
     return c;

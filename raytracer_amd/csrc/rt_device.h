@@ -14,6 +14,17 @@ namespace rtd {
 
 #define RT_DEV __device__ __forceinline__
 
+// A loop count that is a kernel argument, made opaque where it is used.  Why: hipcc (ROCm 7.2) keeps "n > 0" of such a count as
+// a wave mask and forms its negation with a VECTOR compare, under whatever lanes are active at that point; PointLightTracer's
+// mirror loop ends with only the lanes that still bounce, and the light loop that follows then tested that mask against ITS
+// lanes: a wave whose last bouncing lanes had all left took "n_csg_tops > 0" for true in a world without CSG objects and
+// walked a tree that is not there (a GPU memory fault on the first scene with a point light, a mirror and no CSG object).
+// An SGPR value that comes out of an asm statement is compared where it is used, with scalar instructions.
+__device__ __forceinline__ int uniform_count(int n) {
+  asm volatile("" : "+s"(n));
+  return n;
+}
+
 constexpr float PI_F = 3.14159265358979323846f; // std::numbers::pi_v<float>
 constexpr float INF_F = __builtin_inff();
 
@@ -790,7 +801,7 @@ struct ShadeFetch {
 template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = false, bool TAB = false> RT_DEV Hit world_finish_hit(const Scene &s, const Ray &ray, Best best, ShadeFetch *fetch = nullptr) {
   if (fetch)
     fetch->have = false;
-  for (int i = 0; i < s.n_planes; ++i) {
+  for (int i = 0, n_planes = FAST ? s.n_planes : uniform_count(s.n_planes); i < n_planes; ++i) {
     if (FAST && TAB) {
       ConstI32 ids = (ConstI32)(uintptr_t)&s.planes[i].object;
       const int object = ids[0], shape = ids[1];
@@ -829,7 +840,7 @@ template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = fals
   h.t = 0.f;
   h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
   bool csg_won = false;
-  for (int i = 0; i < (CSG ? s.n_csg_tops : 0); ++i) {
+  for (int i = 0, n_tops = !CSG ? 0 : FAST ? s.n_csg_tops : uniform_count(s.n_csg_tops); i < n_tops; ++i) {
     const CsgTop top = s.csg_tops[i];
     Hit c;
     bool csg_hit;
@@ -884,24 +895,24 @@ template <bool FAST, bool CSG = true, bool TT4 = false, bool TAB = false> RT_DEV
   if (FAST && TAB)
     scan_spheres_tab(s, ray, best);
   else
-    scan_spheres<FAST>(s.spheres, s.n_spheres, ray, best);
+    scan_spheres<FAST>(s.spheres, FAST ? s.n_spheres : uniform_count(s.n_spheres), ray, best);
   return world_finish_hit<FAST, false, CSG, TT4, FAST && TAB>(s, ray, best);
 }
 
 // World::on_off_ray_intersection — shapes.hpp:567-578 (only the boolean is used, renderers.hpp:62-69)
 RT_DEV bool world_any_hit(const Scene &s, const Ray &ray) {
   bool hit = false;
-  for (int i = 0; i < s.n_spheres && !hit; ++i) {
+  for (int i = 0, n = uniform_count(s.n_spheres); i < n && !hit; ++i) {
     const RecRegs r = load_rec(s.spheres, i);
     float t;
     hit = sphere_front_t(r, ray, t);
   }
-  for (int i = 0; i < s.n_planes && !hit; ++i) {
+  for (int i = 0, n = uniform_count(s.n_planes); i < n && !hit; ++i) {
     const RecRegs r = load_rec(s.planes, i);
     float t;
     hit = plane_front_t(r, ray, t);
   }
-  for (int i = 0; i < s.n_csg_tops && !hit; ++i) {
+  for (int i = 0, n = uniform_count(s.n_csg_tops); i < n && !hit; ++i) {
     Hit c;
     hit = csg_ray_intersection(s, s.csg_tops[i], ray, c);
   }
@@ -918,7 +929,7 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
   in_ray.tmax = INF_F;
   if (dot3(in_dir, normal) > 0.f)
     return false;
-  for (int i = 0; i < s.n_spheres; ++i) {
+  for (int i = 0, n = uniform_count(s.n_spheres); i < n; ++i) {
     const RecRegs r = load_rec(s.spheres, i);
     float t;
     if (sphere_front_t(r, in_ray, t) && t < 1.f) {
@@ -929,7 +940,7 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
         return false;
     }
   }
-  for (int i = 0; i < s.n_planes; ++i) {
+  for (int i = 0, n = uniform_count(s.n_planes); i < n; ++i) {
     const RecRegs r = load_rec(s.planes, i);
     float t;
     if (plane_front_t(r, in_ray, t) && t < 1.f) {
@@ -940,7 +951,7 @@ RT_DEV bool world_offset_if_visible(const Scene &s, V3 viewer, V3 surface, V3 no
         return false;
     }
   }
-  for (int i = 0; i < s.n_csg_tops; ++i) {
+  for (int i = 0, n = uniform_count(s.n_csg_tops); i < n; ++i) {
     Hit c;
     if (csg_ray_intersection(s, s.csg_tops[i], in_ray, c) && c.t < 1.f && !point_is_close(c.point, surface))
       return false;
@@ -976,6 +987,10 @@ template <bool FAST = false> RT_DEV V3 pigment_eval(const Scene &s, uint32_t pg,
     int row = (int)(v * (float)h);
     if (col >= w) col = w - 1;
     if (row >= h) row = h - 1;
+    // a NaN coordinate (acos of a local z rounded a hair beyond 1 at a sphere's pole) converts to 0 on this hardware and to
+    // INT_MIN on the reference's x86, where it then reads out of bounds (materials.hpp:120-137 clamps only upwards):
+    // defined as index 0 here and in the oracle
+    col = max(col, 0), row = max(row, 0);
     return ld3(s.texels + 3 * ((size_t)s.pigment_tex_offset[pg] + (size_t)row * (size_t)w + (size_t)col));
   }
   return ld3(s.pigment_color1 + 3 * pg);

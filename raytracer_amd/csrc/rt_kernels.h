@@ -55,7 +55,7 @@ template <int MODE> RT_DEV V3 shade_simple(const Scene &s, const RenderParams &p
     ray.tmax = INF_F;
   }
   V3 radiance = add3(mk3(p.ambient[0], p.ambient[1], p.ambient[2]), pigment_eval(s, s.material_emission_pigment[m], u, v));
-  for (int l = 0; l < s.n_lights; ++l) {
+  for (int l = 0, n_lights = uniform_count(s.n_lights); l < n_lights; ++l) {
     V3 in_dir;
     ++rays;
     if (!world_offset_if_visible(s, ld3(s.light_point + 3 * l), h.point, h.normal, in_dir))

@@ -81,9 +81,15 @@ def main():
         images[f"flat_csg_example_240x135_aa{aa}"], _ = render("csg_example", "flat", 240, 135, aa)
         images[f"onoff_csg_example_240x135_aa{aa}"], _ = render("csg_example", "onoff", 240, 135, aa)
     images["flat_demo_path_clock30_160x120_aa1"] = read_pfm(_render_clock30(os.path.join(TMP, "c30.pfm")))
-    # stock (uncapped) pointlight where the reference terminates: must equal the capped render
-    stock, _ = render("demo_path", "pointlight", 160, 120, 1)
-    assert np.array_equal(stock, images["pointlight_demo_path_160x120_aa1"])
+    # Every pointlight fixture once more with the reference's STOCK PointLightTracer (include/renderers.hpp:121-172; --cap 0: no
+    # harness code in the renderer): at these sizes its mirror loop terminates, and the image must equal the
+    # one made through the harness's capped outer loop byte for byte before anything is written.
+    for scene in ("demo_path", "demo_onoff"):
+        for aa in (1, 2):
+            key = f"pointlight_{scene}_160x120_aa{aa}"
+            stock, _ = render(scene, "pointlight", 160, 120, aa, cap=0)
+            assert stock.tobytes() == images[key].tobytes(), f"{key}: the capped outer loop differs from the stock PointLightTracer"
+            meta.setdefault(key, {})["equals_stock_PointLightTracer"] = True
 
     # 4. path mode, the reference's serial PCG: small exact pins + high-spp statistical references
     for scene in ("demo_path", "csg_example"):
