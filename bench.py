@@ -5,20 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" = one full frame of BASELINE.json's metric: --mode path, 1920x1080, AA=4 (16 spp), n_rays=10, roulette=3,
-max-depth=5, on the synthetic N-random-sphere + floor + sky scene of raytracer_amd/synth.py.  Default N = 512:
-3.1e10 rays per frame, about 5 s on one MI355X.  Every object is tested for every ray (World::ray_intersection is a
-linear scan, reference include/shapes.hpp:547-561); a ray = one such closest-hit query.
+Workload (the headline): the synthetic 4096-random-sphere + floor + sky scene (raytracer_amd/synth.py), --mode path,
+1920x1080, AA=4 (16 spp), n_rays=10, roulette=3, max-depth=5.  Every object is tested for every ray (World::ray_intersection is a
+linear scan, reference include/shapes.hpp:547-561); a ray = one such closest-hit query.  A whole frame is 4.04e11 rays, ~270 s
+on one MI355X, so a STEP is one row-cyclic SHARE of it: 1/32 of the rows (rows k, k + 32, k + 64, ...: every share is the same
+mix of sky, floor and sphere rows; shares differ by < 2 % in cost), 1.26e10 rays, ~8.5 s.  Step j renders share
+(j * n_gpus + rank) mod 32: consecutive steps walk through the frame, a run of 32 / n_gpus steps renders all of it, and
+`value` (rays / time) IS the whole-frame rate; `frame_ms_estimate` = 32 x ms_per_step / n_gpus.
 
-With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (a child
-`python -m torch.distributed.run`, decided before anything touches the GPU) and relays rank 0's line.  The frame's rows
-are dealt round-robin row by row (strong scaling: the frame is fixed), each rank renders its bands into HBM and rank 0
-gathers them over RCCL.  Scene and framebuffers are resident in HBM before the timed region.
+With --gpus N every rank renders its own share of the step (per-GPU work is fixed as N grows: "scaling": "weak"; the job is
+still one frame, N shares of it at a time) into HBM and rank 0 gathers the N shares over RCCL into the frame buffer.  With no
+WORLD_SIZE in the environment and N > 1 the script starts its N ranks itself (a child `python -m torch.distributed.run`, decided
+before anything touches the GPU) and relays rank 0's line.  Scene and buffers are resident in HBM before the timed region.
 
-At N = 1 the line also carries `configs`: every BASELINE.json config measured in the same run — C1 (onoff), C2 (flat and
-pointlight), C3, C4 (path on the reference's sample scenes, full size) and C5, the 4096-sphere scene, as ONE 1/16
-row-cyclic slice of its 1920x1080 AA=4 frame (exactly one rank's share of a 16-GPU run; a whole frame is 16 of them,
-~7 minutes on one GPU) — each with its kernel, ray count, kernel ms (HIP events of the same launch) and roofline block.
+At N = 1 the line also carries `configs`: BASELINE.json's configs measured in the same run — C1 (onoff), C2 (flat and
+pointlight), C3, C4 (path on the reference's sample scenes, full size), the full N=512 frame (round 2's default) with and
+without the matrix-core filter — each with its kernel, ray count, kernel ms (HIP events of the same launch) and roofline block.
+configs[4] (3840x2160) is four times the headline frame: 128 shares of this cost.
 
 Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
@@ -53,62 +56,108 @@ F_EPILOGUE = 54.0 + 75.0  # the winner's hit record + scatter / shading (SURVEY.
 F_EXACT_RECORD = 59.0 + 59.0  # large-world kernels: the winner and the sphere the ray leaves, each once more as the reference writes it
 
 
+# CSG trees by SURVEY.md 8d's formula: every ray pays each leaf's test (52 per sphere leaf, 35 per plane leaf as the reference
+# writes them; the truth-table evaluator of the fused kernels: 58 per sphere leaf — transform 33 + a, b, c, disc 19 + both roots 6 —
+# and 13 per plane leaf); a ray that meets the tree also pays, per candidate hit, one inside test per sibling leaf (23) and the
+# re-mapping of point and normal per node (33).  The leaf part is counted; the per-hit part (at most +30 % on samples/csg_example.txt)
+# is data dependent and is NOT counted: the CSG fractions are lower bounds by that much.
+F_CSG_SPHERE_LEAF_TT, F_CSG_PLANE_LEAF_TT = 58.0, 13.0
+
+# Issue cost of one wave64 VALU instruction on gfx950, measured (scripts/microbench/issue_bench.hip, profiles/r3/issue_bench.txt):
+# fp32 add / mul / fma with vector-register operands 2.35 cycles, transcendental 8.2, everything else (compares, selects, min / max,
+# conversions, shifts, integer multiplies, DPP, any VOP3-only form, any form with a scalar-register operand) 4.2.
+VALU_CYCLES_FAST, VALU_CYCLES_TRANS, VALU_CYCLES_OTHER = 2.35, 8.2, 4.2
+SIMDS = 256 * 4
+
+
 def scene_census(scene):
     import numpy as np
     top = scene.objects[scene.objects >= 0]
     n_sph = int(np.sum(scene.shape_kind[top] == 0))
-    return {"spheres": n_sph, "planes": int(len(top)) - n_sph, "csg": int(np.sum(scene.objects < 0))}
+    leaves = []
+    if len(scene.csg_op):
+        in_tree = np.ones(len(scene.shape_kind), dtype=bool)
+        in_tree[top] = False
+        leaves = scene.shape_kind[in_tree]
+    return {"spheres": n_sph, "planes": int(len(top)) - n_sph, "csg": int(np.sum(scene.objects < 0)),
+            "csg_sphere_leaves": int(np.sum(np.asarray(leaves) == 0)), "csg_plane_leaves": int(np.sum(np.asarray(leaves) == 1)),
+            "csg_nodes": int(len(scene.csg_op))}
 
 
 def flops_per_ray(census, kernel: str):
     """-> (executed, algorithmic) fp32 flops of one closest-hit query + shading.  `algorithmic` is the reference's
-    arithmetic as written (52 per sphere test, +7 for the one sphere that is hit, 35 per plane); `executed` is what the
-    kernel named in rt_stats.kernel issues.  CSG trees are not counted in either: a lower bound where a scene has one."""
+    arithmetic as written (52 per sphere test, +7 for the one sphere that is hit, 35 per plane; CSG leaves alike); `executed`
+    is what the kernel named in rt_stats.kernel issues."""
     n_sph, n_pl = census["spheres"], census["planes"]
-    algorithmic = F_SPHERE_WRITTEN * n_sph + 7.0 + F_PLANE_WRITTEN * n_pl + F_EPILOGUE
+    ls, lp = census.get("csg_sphere_leaves", 0), census.get("csg_plane_leaves", 0)
+    algorithmic = F_SPHERE_WRITTEN * (n_sph + ls) + 7.0 + F_PLANE_WRITTEN * (n_pl + lp) + F_EPILOGUE
     if "path_tile<" in kernel:  # register tiles on the fp32 MFMA; the big (sky) sphere is scanned per lane
         executed = F_SPHERE_TILE * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE + F_EXACT_RECORD
     elif "wide<ISO" in kernel:  # register rows in the world-space form; the big (sky) sphere is scanned per lane
         executed = F_SPHERE_WORLD * max(n_sph - 1, 0) + F_SPHERE_OBJECT * min(n_sph, 1) + F_PLANE_FMA * n_pl + F_EPILOGUE + F_EXACT_RECORD
     elif "EXACT" in kernel or "simple" in kernel:  # unfused, the reference's operation order
         executed = algorithmic
-    else:  # k_render_path<FMA...>, wide<GEN>: object-space FMA form
-        executed = F_SPHERE_OBJECT * n_sph + F_PLANE_FMA * n_pl + F_EPILOGUE
+    else:  # k_render_path_wave / k_render_path<FMA...>, wide<GEN>: object-space FMA form; CSG leaves by the truth-table evaluator
+        executed = F_SPHERE_OBJECT * n_sph + F_PLANE_FMA * n_pl + F_CSG_SPHERE_LEAF_TT * ls + F_CSG_PLANE_LEAF_TT * lp + F_EPILOGUE
     return executed, algorithmic
 
 
-def roofline_block(census, kernel, rays, kernel_ms, traffic=None, bvh=False):
+def load_profile(name):
+    """A committed counter summary of round 3 (profiles/r3/<name>_pmc.json, made by scripts/pmc_run.sh: separate rocprofv3 --pmc
+    passes of the same configuration) or None."""
+    path = os.path.join(ROOT, "profiles", "r3", name + "_pmc.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        j = json.load(f)
+    j["_source"] = os.path.relpath(path, ROOT)
+    return j
+
+
+def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
+    """One roofline block.  Every number can be recomputed from this line and the profile it names:
+       frac_executed    = rays x flops_per_ray (what the kernel issues, FMA = 2) / kernel_ms / peak            (<= 1 by construction)
+       frac_algorithmic = rays x algorithmic_flops_per_ray (the reference's arithmetic as written) / kernel_ms / peak
+                          — exceeds 1 where the kernel does the same job with fewer flops (18 instead of 52 per sphere test)
+       achieved / frac  = the executed figures (the contract's field names)
+       traffic          = HBM-side bytes per launch from the PMC counters of `traffic_source` (FETCH_SIZE + WRITE_SIZE, each in its own
+                          rocprofv3 --pmc pass of the same configuration), null when no such profile is committed — never measured in the
+                          timed run itself
+       valu_issue       = for the kernels that are NOT flop-bound (a handful of objects per ray): the bound that applies — the
+                          vector ALU's issue slots.  VALU wave-instructions per ray by class from the profile's SQ_INSTS_VALU* counters x
+                          the measured issue cost of each class, against the SIMD-cycles per ray of this very launch."""
     if bvh:  # the hierarchy skips most of the tests a brute-force flop count assumes: no fraction of a roofline
         return {"bound": "valu", "achieved": None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms,
                 "note": "BVH mode changes the algorithmic work; see DESIGN.md 4.6 for its step counts"}
     executed, algorithmic = flops_per_ray(census, kernel)
     ach = rays * executed / (kernel_ms * 1e-3) / 1e12
-    # the tile kernel's flops run on the binary32 MFMA, whose dense peak equals the vector fp32 peak (it uses the same lanes)
-    return {"bound": "mfma" if "path_tile<" in kernel else "valu", "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
-            "traffic": traffic, "kernel": kernel, "flops_per_ray": executed, "rays_per_launch": rays, "kernel_ms": kernel_ms,
-            "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": rays * algorithmic / (kernel_ms * 1e-3) / 1e12,
-            "note": "achieved / frac count the flops the kernel issues (FMA = 2); algorithmic_* count the reference's arithmetic "
-                    "as written for the same rays (52 flops per sphere test) and may exceed the peak"}
-
-
-def pmc_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel, from the committed counter passes of THIS configuration
-    (scripts/pmc_run.sh -> profiles/r2/n512_pmc.json: FETCH_SIZE and WRITE_SIZE in KB, each in its own rocprofv3 --pmc
-    pass, summed over the launches of one run and divided by their number).  None for any other configuration:
-    counters cannot be read from inside the timed run."""
-    default = (not args.bvh and not args.valu_only and args.spheres == 512 and args.width == 1920 and args.height == 1080 and args.aa == 4 and not args.scene
-               and args.n_rays == 10 and args.roulette == 3 and args.max_depth == 5)
-    if not default:
-        return None
-    for rel in (("profiles", "r2", "n512_pmc.json"), ("profiles", "r1", "g_n512_pmc.json")):
-        path = os.path.join(ROOT, *rel)
-        if os.path.exists(path):
-            with open(path) as f:
-                j = json.load(f)
-            c = j["counters"]
-            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / float(j.get("launches", 2))
-    return None
+    alg = rays * algorithmic / (kernel_ms * 1e-3) / 1e12
+    out = {"bound": "mfma" if "path_tile<" in kernel else "valu", "peak_kind": "fp32, vector = matrix: v_mfma_f32_32x32x2_f32 runs on the VALU's fp32 lanes (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)",
+           "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
+           "frac_executed": ach / FP32_VALU_PEAK_TFLOPS, "frac_algorithmic": alg / FP32_VALU_PEAK_TFLOPS,
+           "flops_per_ray": executed, "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": alg,
+           "traffic": None, "traffic_source": None, "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms}
+    if census.get("csg"):
+        out["csg_counted"] = "leaf tests only (SURVEY.md 8d); per-hit inside tests and node re-mapping not counted: fractions are lower bounds by at most 30 %"
+    if profile is not None:
+        c, launches = profile["counters"], float(profile.get("launches", 1))
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out["traffic"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
+            out["traffic_source"] = profile["_source"]
+        if "SQ_INSTS_VALU_FMA_F32" in c:
+            n = float(profile["rays_per_launch"]) * launches
+            fast = (c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / n
+            trans = c["SQ_INSTS_VALU_TRANS_F32"] / n
+            total = c["SQ_INSTS_VALU"] / n
+            model = fast * VALU_CYCLES_FAST + trans * VALU_CYCLES_TRANS + (total - fast - trans) * VALU_CYCLES_OTHER
+            clk = profile.get("derived", {}).get("clock_ghz", 2.3)
+            measured = kernel_ms * 1e-3 * clk * 1e9 * SIMDS / rays
+            out["valu_issue"] = {"valu_wave_instr_per_ray": total, "fp32_add_mul_fma_per_ray": fast, "transcendental_per_ray": trans,
+                                 "modelled_valu_cycles_per_ray": model, "simd_cycles_per_ray_this_launch": measured, "clock_ghz": clk,
+                                 "frac": model / measured, "source": profile["_source"],
+                                 "note": "frac near 1 = the vector ALU issues all the time; 'other' is priced at 4.2 cycles although its plain moves and logic ops issue at 2.3: an upper estimate"}
+    return out
 
 
 def cpu_baseline(scene, text, args):
@@ -120,7 +169,7 @@ def cpu_baseline(scene, text, args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from raytracer_amd import abi
-    w, h, aa = args.cpu_width, args.cpu_height, 1
+    w, h, aa = args.cpu_width, args.cpu_height, 1  # defaults: 12x7 on the 4096-sphere world: ~15 s of the reference + ~20 s of the port on one core of the GPU box's host
     cfg = O.make_cfg(w, h, "path", spp_edge=aa, n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth,
                      seq_number=54, rng_mode=abi.RT_RNG_SERIAL_REFERENCE)
     t0 = time.perf_counter()
@@ -157,8 +206,8 @@ def self_launch(args):
 
 
 def measure_configs(device, log):
-    """BASELINE.json's five configs, each as one sub-record (N = 1 only).  Times are HIP events around the very launch
-    whose ray count is reported (rt_stats of the same call); C1-C4: best of 3 after one warm-up launch."""
+    """BASELINE.json's configs C1-C4 and the full N=512 frame, each as one sub-record (N = 1 only).  Times are HIP events around the
+    very launch whose ray count is reported (rt_stats of the same call); C1-C4: best of 3 after one warm-up launch."""
     import torch
     from raytracer_amd.scene import FlatScene
     from raytracer_amd.synth import synthetic_scene
@@ -166,7 +215,7 @@ def measure_configs(device, log):
     golden = os.path.join(ROOT, "tests", "golden")
     recs = []
 
-    def run(cid, label, scene, mode, w, h, aa, rows=None, reps=3, note=None):
+    def run(cid, label, scene, mode, w, h, aa, rows=None, reps=3, note=None, profile=None):
         world = DeviceWorld(scene, device.index)
         tracer = GpuImageTracer(w, h, scene.camera, aa)
         rows = rows or RowBands.whole(h)
@@ -180,7 +229,7 @@ def measure_configs(device, log):
         rec = {"id": cid, "workload": label, "objects": scene.count("n_objects"), "kernel": kernel, "grid": int(st.grid), "block": int(st.block),
                "samples": int(st.samples), "rays": int(st.rays), "capped_samples": int(st.capped_samples), "kernel_ms": best,
                "Mrays_per_s": st.rays / best / 1e3,
-               "roofline": roofline_block(scene_census(scene), kernel, int(st.rays), best)}
+               "roofline": roofline_block(scene_census(scene), kernel, int(st.rays), best, load_profile(profile) if profile else None)}
         if note:
             rec["note"] = note
         world.close()
@@ -193,20 +242,15 @@ def measure_configs(device, log):
     run("C1", "samples/demo_onoff_tracing.txt, --mode onoff, 1280x960, AA=1", onoff, RenderMode("onoff"), 1280, 960, 1)
     run("C2-flat", "samples/demo_path_tracing.txt, --mode flat, 1280x960, AA=2", demo, RenderMode("flat"), 1280, 960, 2)
     run("C2-pointlight", "samples/demo_path_tracing.txt, --mode pointlight, 1280x960, AA=2", demo, RenderMode("pointlight"), 1280, 960, 2)
-    run("C3", "samples/demo_path_tracing.txt, --mode path 10/3/5, 1280x960, AA=2", demo, RenderMode("path"), 1280, 960, 2)
-    run("C4", "samples/csg_example.txt, --mode path 10/3/5, 1920x1080, AA=4", csg, RenderMode("path"), 1920, 1080, 4,
-        note="roofline counts the two top-level objects only (the CSG tree's leaf and inside tests are not counted): a lower bound")
-    big = synthetic_scene(4096)[0]
-    run("C5-slice", "synthetic 4096-random-sphere + floor + sky, --mode path 10/3/5, 1920x1080, AA=4: rows 0, 16, 32, ... "
-        "(one 1/16 row-cyclic slice = one rank's share of 16; a whole frame is 16 such launches)", big, RenderMode("path"), 1920, 1080, 4,
-        rows=RowBands.cyclic(1080, 0, 16, band_rows=1), reps=1,
-        note="whole-frame estimate = 16 x kernel_ms (slices differ by < 1 %, profiles/r1/h_full_n4096_1080p_aa4.json); "
-             "configs[4]'s 3840x2160 frame is 64 slices of this cost")
-    recs[-1]["frame_ms_estimate_one_gpu"] = 16.0 * recs[-1]["kernel_ms"]
-    # The headline workload once more WITHOUT any MFMA instruction (BASELINE.json's north_star expected no dense contraction
-    # in this path; the brute-force ray x sphere filter turned out to be one): the vector-ALU filter kernel.
-    run("N512-valu-only", "the bench default (synthetic 512-sphere scene, path 10/3/5, 1920x1080, AA=4) with RT_FLAG_VALU_ONLY: "
-        "the sphere filter on the vector ALU, no matrix-core instruction", synthetic_scene(512)[0], RenderMode("path", valu_only=True), 1920, 1080, 4, reps=1)
+    run("C3", "samples/demo_path_tracing.txt, --mode path 10/3/5, 1280x960, AA=2", demo, RenderMode("path"), 1280, 960, 2, profile="c3")
+    run("C4", "samples/csg_example.txt, --mode path 10/3/5, 1920x1080, AA=4", csg, RenderMode("path"), 1920, 1080, 4, profile="c4")
+    small = synthetic_scene(512)[0]
+    run("N512-frame", "synthetic 512-random-sphere + floor + sky, --mode path 10/3/5, 1920x1080, AA=4, the WHOLE frame in one launch (round 2's bench default)",
+        small, RenderMode("path"), 1920, 1080, 4, reps=1, profile="n512")
+    # The same frame WITHOUT any MFMA instruction (BASELINE.json's north_star expected no dense contraction in this path; the
+    # brute-force ray x sphere filter turned out to be one): the vector-ALU filter kernel.
+    run("N512-valu-only", "the same frame with RT_FLAG_VALU_ONLY: the sphere filter on the vector ALU, no matrix-core instruction",
+        small, RenderMode("path", valu_only=True), 1920, 1080, 4, reps=1)
     return recs
 
 
@@ -218,20 +262,21 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=4)
-    ap.add_argument("--spheres", type=int, default=512)
+    ap.add_argument("--spheres", type=int, default=4096)
+    ap.add_argument("--shares", type=int, default=32, help="a step renders 1 / SHARES of the frame's rows per rank (row-cyclic); 1 = the whole frame per step")
     ap.add_argument("--scene", default=None, choices=["demo_onoff", "demo_path", "csg_example"],
                     help="one of the reference's sample scenes (flattened fixture in tests/golden/) instead of the synthetic one")
     ap.add_argument("--n_rays", type=int, default=10)
     ap.add_argument("--roulette", type=int, default=3)
     ap.add_argument("--max-depth", dest="max_depth", type=int, default=5)
-    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=96)
-    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=54)
+    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=12)
+    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1-C5) of the N=1 line")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records of the N=1 line")
     ap.add_argument("--bvh", action="store_true",
                     help="RT_FLAG_ACCEL_BVH: not the reference's algorithmic work, so the line carries no roofline fraction")
     ap.add_argument("--valu-only", action="store_true", help="RT_FLAG_VALU_ONLY: the large-world sphere filter on the vector ALU (no MFMA instruction)")
-    ap.add_argument("--save-pfm", default=None, help="write the last frame here (rank 0)")
+    ap.add_argument("--save-pfm", default=None, help="write the frame buffer here at the end (rank 0; the rows of shares not rendered are zero)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices, gather staged through the host)")
     args = ap.parse_args()
@@ -241,7 +286,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd.dist import gather_rows, max_local_rows, rank_rows
+    from raytracer_amd.dist import gather_shares, share_rows
     from raytracer_amd.synth import synthetic_scene
     from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
 
@@ -250,6 +295,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.shares < 1 or args.shares > args.height:
+        raise SystemExit("--shares must be in 1 ... height")
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -269,20 +316,24 @@ def main():
     world = DeviceWorld(scene, dev_index)
     tracer = GpuImageTracer(args.width, args.height, scene.camera, args.aa)
     mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh, valu_only=args.valu_only)
-    rows = rank_rows(args.height, rank, world_size)
-    local = torch.empty((rows.n_local_rows, args.width, 3), dtype=torch.float32, device=device)
-    full = torch.empty((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
-    padded = parts = None
+    max_rows = -(-args.height // args.shares)
+    local = torch.empty((max_rows, args.width, 3), dtype=torch.float32, device=device)
+    full = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
     gather_dev = torch.device("cpu") if staged else device
-    full_g = torch.empty((args.height, args.width, 3), dtype=torch.float32) if (staged and rank == 0) else full
-    if world_size > 1:
-        padded = torch.empty((max_local_rows(args.height, world_size), args.width, 3), dtype=torch.float32, device=gather_dev)
-        parts = [torch.empty_like(padded) for _ in range(world_size)] if rank == 0 else None
+    padded = torch.empty((max_rows, args.width, 3), dtype=torch.float32, device=gather_dev) if world_size > 1 else None
+    parts = [torch.empty_like(padded) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
 
-    def gather():
-        gather_rows(local.cpu() if staged else local, args.height, full_g, padded=padded, parts=parts)
-        if staged and rank == 0:
-            full.copy_(full_g)
+    def rows_of(step, r):
+        return share_rows(args.height, step, r, world_size, args.shares)
+
+    def render(step, want_stats):
+        rows = rows_of(step, rank)
+        tracer.fire_all_rays(world, mode, rows, out=local[: rows.n_local_rows], want_stats=want_stats)
+        return rows
+
+    def gather(step):
+        rows = rows_of(step, rank)
+        gather_shares((local.cpu() if staged else local)[: rows.n_local_rows], [rows_of(step, r) for r in range(world_size)], full, padded, parts)
 
     def barrier():
         if world_size > 1:
@@ -292,74 +343,86 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    log(f"scene uploaded: {scene.count('n_objects')} objects; frame {args.width}x{args.height} AA={args.aa}")
-    # Warm-up.  The first pass also reads the launch's statistics: the ray count of a frame is deterministic (streams
-    # depend only on the sample index), so it holds for every timed step.
-    tracer.fire_all_rays(world, mode, rows, out=local, want_stats=True)
-    gather()
+    log(f"scene uploaded: {scene.count('n_objects')} objects; frame {args.width}x{args.height} AA={args.aa}, {args.shares} shares, {world_size} rank(s)")
+    # Warm-up.  Step numbering continues into the timed steps, so the run walks through the frame's shares.
+    # The first pass also names the kernel.
+    render(0, True)
+    gather(0)
     st = tracer.last_stats
-    rays_local, samples_local = int(st.rays), int(st.samples)
-    kernel_name = st.kernel.decode() if rows.n_local_rows else ""
-    log(f"stats pass: {rays_local} rays, {samples_local} samples, kernel {st.kernel_ms:.1f} ms, {kernel_name} grid {st.grid} x {st.block}")
-    for _ in range(max(args.warmup - 1, 0)):
-        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
-        gather()
+    kernel_name = st.kernel.decode()
+    log(f"first pass: {int(st.rays)} rays, {int(st.samples)} samples, kernel {st.kernel_ms:.1f} ms, {kernel_name} grid {st.grid} x {st.block}")
+    import hashlib
+    share0_sha = hashlib.sha256(local[: rows_of(0, rank).n_local_rows].cpu().numpy().tobytes()).hexdigest() if rank == 0 else None
+    for k in range(1, args.warmup):
+        render(k, False)
+        gather(k)
     torch.cuda.synchronize()
     barrier()
 
+    first = max(args.warmup, 1)
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    rays_local = samples_local = 0
     for k in range(args.steps):
         ev[k][0].record()  # torch's current stream == the stream rt_render launches on
-        tracer.fire_all_rays(world, mode, rows, out=local, want_stats=False)
+        render(first + k, True)  # with the launch's tallies: shares differ slightly in rays (one 528-byte copy after the kernel, ~20 us of a step)
+        rays_local += int(tracer.last_stats.rays)
+        samples_local += int(tracer.last_stats.samples)
         ev[k][1].record()
-        gather()
+        gather(first + k)
         ev[k][2].record()  # after the gather: torch makes the current stream wait for the collective
         if args.steps > 1:
             torch.cuda.current_stream().synchronize()
-            log(f"step {k + 1}/{args.steps} done")
+        log(f"step {k + 1}/{args.steps} done: {int(tracer.last_stats.rays)} rays, kernel {tracer.last_stats.kernel_ms:.1f} ms")
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
     gather_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps  # on rank 0 this includes waiting for the slowest rank
 
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=gather_dev)
+    t = torch.tensor([elapsed, kernel_ms, -kernel_ms], dtype=torch.float64, device=gather_dev)
     r = torch.tensor([rays_local, samples_local], dtype=torch.int64, device=gather_dev)
     g = torch.tensor([gather_ms], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         dist.all_reduce(g, op=dist.ReduceOp.MIN)  # the rank that finished rendering last waits for nobody: the transfer itself
-    elapsed, kernel_ms_max = float(t[0]), float(t[1])
+    elapsed, kernel_ms_max, kernel_ms_min = float(t[0]), float(t[1]), -float(t[2])
     rays_total, samples_total = int(r[0]), int(r[1])
 
     if rank == 0:
         census = scene_census(scene)
+        default_workload = (not args.scene and args.spheres == 4096 and args.width == 1920 and args.height == 1080 and args.aa == 4 and args.shares == 32
+                            and (args.n_rays, args.roulette, args.max_depth) == (10, 3, 5) and not args.bvh and not args.valu_only)
+        rays_per_step_rank0 = rays_local / args.steps
         out = {
-            "metric": "path-mode Mrays/s (frame ms in ms_per_step), 1920x1080 AA=4",
-            "value": rays_total * args.steps / elapsed / 1e6,
+            "metric": "path-mode Mrays/s (frame ms in frame_ms_estimate), 1920x1080 AA=4",
+            "value": rays_total / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"samples/{args.scene} (reference sample scene)" if args.scene else
                                     f"synthetic {args.spheres}-random-sphere + floor + sky scene") + f", --mode path, "
                                    f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "
-                                   f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else ""),
-                       "objects": scene.count("n_objects"), "top_level": census, "samples_per_frame": samples_total,
-                       "rays_per_frame": rays_total, "rays_per_sample": rays_total / max(samples_total, 1),
-                       "parallelism": f"rows-cyclic-x{world_size}" if world_size > 1 else "single"},
-            "kernel_ms_per_step_max_rank": kernel_ms_max,
+                                   f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else "") +
+                                   (f"; one step = one row-cyclic share of 1/{args.shares} of the frame per GPU (rows k, k + {args.shares}, ...), "
+                                    f"consecutive steps render consecutive shares" if args.shares > 1 else "; one step = the whole frame"),
+                       "objects": scene.count("n_objects"), "top_level": {k: census[k] for k in ("spheres", "planes", "csg")},
+                       "shares_per_frame": args.shares, "samples_per_step": samples_total // args.steps,
+                       "rays_per_step": rays_total / args.steps, "rays_per_sample": rays_total / max(samples_total, 1),
+                       "parallelism": f"{world_size} ranks x 1 share per step, RCCL gather to rank 0" if world_size > 1 else "single"},
+            "frame_ms_estimate": elapsed / args.steps * 1e3 * args.shares / world_size,
+            "kernel_ms_per_step": {"max_over_ranks": kernel_ms_max, "min_over_ranks": kernel_ms_min},
             "gather_ms_per_step": {"rank0_including_wait_for_slowest_rank": gather_ms, "min_over_ranks": float(g[0])},
-            # dominant kernel on rank 0's share: ITS rays / ITS duration (k_resolve rides in the same interval, < 0.1 %)
-            "roofline": roofline_block(census, kernel_name, rays_local, kernel_ms, pmc_traffic(args) if world_size == 1 else None, bvh=args.bvh),
+            # dominant kernel on rank 0's shares: ITS rays / ITS duration (k_resolve rides in the same interval, < 0.1 %)
+            "roofline": roofline_block(census, kernel_name, rays_per_step_rank0, kernel_ms,
+                                       load_profile("n4096_share") if (default_workload and world_size == 1) else None, bvh=args.bvh),
+            # share 0 as rank 0 rendered it in the first pass: bit-identical for any number of ranks and any kernel shape
+            "share0_sha256": share0_sha,
         }
-        import hashlib
-        # the assembled frame is bit-identical for any number of ranks: compare this across --gpus runs
-        out["frame_sha256"] = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest()
         if args.save_pfm:
             img = full.cpu().numpy()
             with open(args.save_pfm, "wb") as f:

@@ -27,6 +27,33 @@ def max_local_rows(height: int, world: int, band_rows: int = BAND_ROWS) -> int:
     return max(rank_rows(height, r, world, band_rows).n_local_rows for r in range(world))
 
 
+def share_rows(height: int, step: int, rank: int, world: int, n_shares: int) -> RowBands:
+    """One frame cut into n_shares row-cyclic shares (share k = rows k, k + n_shares, ...), dealt to the ranks step by step:
+    in step `step` rank `rank` renders share (step * world + rank) mod n_shares.  Every share is the same mix of the frame's
+    rows (they differ by < 2 % in cost), so the ranks of a step are balanced and a run of n_shares / world steps is the frame."""
+    return RowBands.cyclic(height, (step * world + rank) % n_shares, n_shares, 1)
+
+
+def gather_shares(local: torch.Tensor, rows_of_rank: list, full_out: torch.Tensor | None, padded: torch.Tensor, parts: list | None):
+    """Gathers the ranks' buffers of one step (rank r rendered rows_of_rank[r], any RowBands) to rank 0 and places their rows
+    in full_out.  padded: [max rows, W, 3] staging on every rank; parts: on rank 0 a list of `world` such tensors."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        idx = torch.as_tensor(rows_of_rank[0].image_rows(), device=full_out.device, dtype=torch.long)
+        full_out.index_copy_(0, idx, local[: rows_of_rank[0].n_local_rows])
+        return full_out
+    padded[: local.shape[0]].copy_(local)
+    if rank == 0:
+        dist.gather(padded, gather_list=parts, dst=0)
+        for r in range(world):
+            idx = torch.as_tensor(rows_of_rank[r].image_rows(), device=full_out.device, dtype=torch.long)
+            full_out.index_copy_(0, idx, parts[r][: rows_of_rank[r].n_local_rows].to(full_out.device))
+        return full_out
+    dist.gather(padded, gather_list=None, dst=0)
+    return None
+
+
 def gather_rows(local: torch.Tensor, height: int, full_out: torch.Tensor | None, band_rows: int = BAND_ROWS,
                 padded: torch.Tensor | None = None, parts: list | None = None):
     """Gathers every rank's band buffer to rank 0 and assembles the image there.
