@@ -161,8 +161,9 @@ typedef struct rt_render_cfg {
    */
   int32_t max_mirror_bounces;
   /*
-   * RT_RNG_PER_NODE_STREAMS: every pixel sample owns a PCG stream derived from
-   * (seq_number, global sample index); image independent of GPU count.  Statistical parity.
+   * RT_RNG_PER_NODE_STREAMS: every RAY owns a PCG stream — a camera ray's from (seq_number, global sample index), a
+   * scattered ray's from its parent's stream and its index among the children; image independent of GPU count,
+   * grid and kernel shape.  Statistical parity.
    * RT_RNG_SERIAL_REFERENCE is not available on the device (the reference consumes one stream
    * serially over the whole image); the value exists so that the CPU oracle can be asked for it.
    */
@@ -260,8 +261,9 @@ RT_API rt_status rt_render(rt_scene *scene, const rt_camera *camera, const rt_re
  * spp_edge > 1, the node stacks of path mode) is carved out of one file-scope device array of
  * RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call makes no
  * hipMalloc / hipFree.  Limits: 1024 + width * n_local_rows * spp_edge^2 * 12 bytes (spp_edge > 1 only) + in path mode
- * at least one node stack per compute unit (13 * 4 * block * max(max_depth, 1) bytes each, block = 256 lanes for small
- * worlds) must fit; otherwise RT_ERR_INVALID_ARGUMENT with the sizes in rt_last_error() — render fewer rows per
+ * at least one workgroup's node stacks per compute unit must fit: 64 bytes (one 16-word node record) x block x
+ * max(max_depth, 1) per workgroup — 64 x block when n_rays == 1 — with block = 256 lanes for small worlds and
+ * 64 ... 512 for large ones (rt_stats.block); otherwise RT_ERR_INVALID_ARGUMENT with the sizes in rt_last_error() — render fewer rows per
  * call (band_* fields) or use rt_render.  All calls on one GPU share that GPU's array (whatever the scene handle):
  * calls that overlap on one GPU race; order them on one stream or synchronise between them. */
 #define RT_NOALLOC_SCRATCH_BYTES (128u * 1024u * 1024u)
@@ -306,7 +308,8 @@ typedef struct rt_multi rt_multi; /* opaque */
 typedef struct rt_multi_timing {
   int32_t n_ranks;
   float slowest_render_ms;                      /* the frame's kernel time: max over ranks                               */
-  float gather_ms;                              /* from the last rank's render finishing to the assembled frame (host clock) */
+  float gather_ms;                              /* transfer + placement: HIP events on the first device's stream, which waits  */
+                                                /* for every rank's render before the gather starts                         */
   float render_ms[RT_MULTI_MAX_TIMED_RANKS];    /* per rank, HIP events on its stream                                     */
   uint64_t rays[RT_MULTI_MAX_TIMED_RANKS];      /* per rank                                                               */
 } rt_multi_timing;
@@ -322,6 +325,12 @@ RT_API rt_status rt_multi_render(rt_multi *multi, const rt_camera *camera, const
 /* The same into host memory (HdrImage::pixels): one device-to-host copy from the first rank's device. */
 RT_API rt_status rt_multi_render_host(rt_multi *multi, const rt_camera *camera, const rt_render_cfg *cfg, float *rgb_out_host,
                                       rt_stats *stats, rt_multi_timing *timing);
+/* ... with ImageTracer::fire_all_rays' progress reports (include/cameras.hpp:249, once per image column there): `progress`
+ * is called with n_reports rising fractions in (0, 1] while the ranks render — the share of the frame's pixel samples their
+ * sample queues have handed out, read by small copies on a second stream per device — the last one (1.0) when the frame is in
+ * rgb_out_host.  progress may be NULL. */
+RT_API rt_status rt_multi_render_frame_host(rt_multi *multi, const rt_camera *camera, const rt_render_cfg *cfg, float *rgb_out_host,
+                                            int n_reports, rt_progress_fn progress, void *user, rt_stats *stats, rt_multi_timing *timing);
 
 /* Batch closest-hit --------------------------------------------------------------------------------
  * Replaces: World::ray_intersection (include/shapes.hpp:547-561) for n rays at once; one ray per

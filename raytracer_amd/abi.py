@@ -128,6 +128,8 @@ PROTOTYPES = {
                                   C.POINTER(rt_multi_timing)]),
     "rt_multi_render_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.POINTER(rt_stats),
                                        C.POINTER(rt_multi_timing)]),
+    "rt_multi_render_frame_host": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.POINTER(rt_stats), C.POINTER(rt_multi_timing)]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_offset_if_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rt_aa_jitter": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -822,13 +822,13 @@ namespace {
 // or with tiny spheres would silently lose accuracy, so such worlds take the object-space kernel (k_render_path_wide<GEN>:
 // the ray is mapped into each sphere's frame first, nothing cancels).  Ray origins are bounded by the camera's and by the
 // spheres' own reach (rays leaving far points of an unbounded plane are not: their share of a frame is negligible).
-bool world_filter_ok(const rt_scene *sc, const rt_camera *cam) {
+bool world_filter_ok(const rt_scene *sc, const rt_camera *cam, float resolved_asp) {
   const float *m = cam->fwd;
   const double col0 = std::sqrt(double(m[0]) * m[0] + double(m[3]) * m[3] + double(m[6]) * m[6]);
   const double col1 = std::sqrt(double(m[1]) * m[1] + double(m[4]) * m[4] + double(m[7]) * m[7]);
   const double col2 = std::sqrt(double(m[2]) * m[2] + double(m[5]) * m[5] + double(m[8]) * m[8]);
   const double shift = std::sqrt(double(m[9]) * m[9] + double(m[10]) * m[10] + double(m[11]) * m[11]);
-  const double asp = cam->has_asp_ratio ? std::fabs(double(cam->asp_ratio)) : 2.0;
+  const double asp = std::fabs(double(resolved_asp)); // what the render uses: the camera's own ratio or width / height
   const double cam_reach = shift + std::max(1.0, std::fabs(double(cam->distance))) * col0 + asp * col1 + col2; // both camera kinds
   const double o = std::max(cam_reach, sc->wide_reach), c = sc->wide_reach;
   const double err = std::ldexp(o * o + c * c, -22);
@@ -927,7 +927,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     const bool small_tables = tab[0] <= L::SHAPES && tab[1] <= L::MATERIALS && tab[2] <= L::PIGMENTS && tab[3] <= L::CSG_LEAVES &&
                               tab[4] <= L::CSG_PATH && tab[5] <= L::CSG_NODES && tab[6] <= L::CSG_PROG && sc->dev.n_csg_tops <= L::CSG_TOPS;
     const bool use_bvh = (cfg->flags & RT_FLAG_ACCEL_BVH) != 0 && sc->dev.n_bvh_nodes > 0;
-    static const int wide_min = [] { const char *e = std::getenv("RT_WIDE_MIN"); return e && *e ? std::atoi(e) : RT_WIDE_MIN_SPHERES; }(); // tuning aid
+#ifdef RT_TUNING // -DRT_TUNING builds only (scripts/build_variant.sh): kernel selection overridden from the environment for A/B runs
+    static const int wide_min = [] { const char *e = std::getenv("RT_WIDE_MIN"); return e && *e ? std::atoi(e) : RT_WIDE_MIN_SPHERES; }();
+#else
+    constexpr int wide_min = RT_WIDE_MIN_SPHERES;
+#endif
     const bool use_wide = !exact && !use_bvh && sc->dev.n_wide >= wide_min; // measured: see RT_WIDE_MIN_SPHERES
     // Small worlds with small lookup tables (every sample scene of the reference): the pool run wave by wave (rt_wavepath.h)
     const bool use_wave = small_tables && !use_bvh && !use_wide;
@@ -937,7 +941,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
       // SIMD, 94 at 5, 80 at 6 with 2 spilled; 25 KB of LDS, so 6 workgroups fit a CU): measured on C3, waves per SIMD
       // 4 -> 15.0, 5 -> 14.1, 6 -> 13.8 ms (the kernel with the CSG code: 15.6 at 4, its best).
       // With CSG objects: 5 (96 VGPRs) beats 4 and 6 — measured on C4: 46.1 / 43.7 / 62.7 ms.
-      static const int occ_env = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 0; }(); // tuning aid
+#ifdef RT_TUNING
+      static const int occ_env = [] { const char *e = std::getenv("RT_WAVEPATH_OCC"); return e ? std::atoi(e) : 0; }();
+#else
+      constexpr int occ_env = 0;
+#endif
       const bool csg = sc->dev.n_csg_tops > 0;
       const int occ = occ_env ? occ_env : (csg ? 5 : RT_WAVE_OCC_NO_CSG);
 #define RT_WAVE_K(FAST, OCC, CSG) reinterpret_cast<const void *>(rtd::k_render_path_wave<FAST, OCC, CSG>)
@@ -994,7 +1002,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     // Large worlds: spheres in registers, rays through LDS (see k_render_path_wide).
     const int rows = sc->dev.wide_rows;
     if (use_wide) {
-      const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) && world_filter_ok(sc, cam);
+      const bool iso = sc->dev.spheres_all_iso && !(cfg->flags & RT_FLAG_OBJECT_SPACE_SPHERES) && world_filter_ok(sc, cam, p.cam.asp);
       // K rows per lane within 128 VGPRs (4 waves per SIMD measured faster than more rows per lane at 2),
       // as few waves per workgroup as that allows; more rows than 8 waves hold: several register passes.
       const int kmax = iso ? 8 : 4;
@@ -1012,7 +1020,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
         // 1270 / 1403 / 1373): 1 up to 16 tiles, 2 up to 32, 4 beyond — small workgroups wait less at their two barriers, until
         // the passes (sphere registers reloaded from L2) get too many.
         const int tiles = sc->dev.n_wide_tiles;
-        static const int w_env = [] { const char *e = std::getenv("RT_TILE_W"); return e && *e ? std::atoi(e) : 0; }(); // tuning aid
+#ifdef RT_TUNING
+        static const int w_env = [] { const char *e = std::getenv("RT_TILE_W"); return e && *e ? std::atoi(e) : 0; }();
+#else
+        constexpr int w_env = 0;
+#endif
         waves = 1;
         while (waves < 4 && tiles > waves * 16)
           waves *= 2;
@@ -1212,6 +1224,15 @@ rt_status rt_render_frame_host(rt_scene *sc, const rt_camera *cam, const rt_rend
   Workspace ws;
   LaunchInfo info;
   ws.info = &info;
+  // The slices are queued back to back and differ by a row in height: size the sample buffer for the tallest one now, so
+  // that no later slice re-allocates (hipFree would wait for the slices in flight and stall the queue).
+  if (cfg->spp_edge > 1) {
+    const size_t tallest = static_cast<size_t>((cfg->height + n_slices - 1) / n_slices);
+    if (rt_status st = ensure(sc->samples, tallest * cfg->width * static_cast<size_t>(cfg->spp_edge) * cfg->spp_edge * 3 * sizeof(float)))
+      return st;
+  }
+  if (poll) // the queue head the poll reads must not be the previous frame's: zero it before anything is launched
+    RT_HIP(hipMemset(sc->counters, 0, sizeof(unsigned long long)));
   RT_HIP(hipEventRecord(sc->slice_events[0], stream));
   std::vector<int> row_end(static_cast<size_t>(n_slices));
   for (int i = 0; i < n_slices; ++i) { // all slices are queued before the first report: the GPU never waits for the host
@@ -1347,6 +1368,8 @@ struct rt_multi {
   std::vector<rt_scene *> scenes;       // one replica of the World per rank
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> begun, done;  // per rank: around its render
+  std::vector<hipStream_t> poll_streams; // per rank: small copies of the sample-queue head while its kernel runs (progress)
+  hipEvent_t gather_begin = nullptr, gather_end = nullptr; // on devices[0]'s stream: around transfer + placement
   std::vector<DeviceBuffer> bands;      // per rank, on its device: its rows, compact
   std::vector<DeviceBuffer> landing;    // per rank >= 1, on devices[0]: where its band arrives
   DeviceBuffer frame;                   // on devices[0]: rt_multi_render_host's frame
@@ -1367,6 +1390,7 @@ void rt_multi_destroy(rt_multi *m) {
     if (r < m->streams.size() && m->streams[r]) (void)hipStreamDestroy(m->streams[r]);
     if (r < m->begun.size() && m->begun[r]) (void)hipEventDestroy(m->begun[r]);
     if (r < m->done.size() && m->done[r]) (void)hipEventDestroy(m->done[r]);
+    if (r < m->poll_streams.size() && m->poll_streams[r]) (void)hipStreamDestroy(m->poll_streams[r]);
     if (r < m->bands.size() && m->bands[r].ptr) (void)hipFree(m->bands[r].ptr);
     if (r < m->scenes.size()) rt_scene_destroy(m->scenes[r]);
   }
@@ -1375,6 +1399,8 @@ void rt_multi_destroy(rt_multi *m) {
     for (DeviceBuffer &b : m->landing)
       if (b.ptr) (void)hipFree(b.ptr);
     if (m->frame.ptr) (void)hipFree(m->frame.ptr);
+    if (m->gather_begin) (void)hipEventDestroy(m->gather_begin);
+    if (m->gather_end) (void)hipEventDestroy(m->gather_end);
   }
   delete m;
 }
@@ -1409,12 +1435,15 @@ rt_status rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_d
     for (size_t q = 0; q < r; ++q)
       distinct = distinct && m->devices[q] != m->devices[r];
   m->scenes.assign(n, nullptr), m->streams.assign(n, nullptr), m->begun.assign(n, nullptr), m->done.assign(n, nullptr);
+  m->poll_streams.assign(n, nullptr);
   m->bands.assign(n, DeviceBuffer{}), m->landing.assign(n, DeviceBuffer{});
   for (size_t r = 0; r < n; ++r) {
     if (rt_status st = rt_scene_create(desc, m->devices[r], &m->scenes[r]))
       return bail(st);
     DeviceGuard guard(m->devices[r]);
     if (guard.err != hipSuccess || hipStreamCreateWithFlags(&m->streams[r], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->poll_streams[r], hipStreamNonBlocking) != hipSuccess ||
+        (r == 0 && (hipEventCreate(&m->gather_begin) != hipSuccess || hipEventCreate(&m->gather_end) != hipSuccess)) ||
         hipEventCreate(&m->begun[r]) != hipSuccess || hipEventCreate(&m->done[r]) != hipSuccess)
       return bail(fail(RT_ERR_HIP, "rt_multi_create: stream / event creation failed"));
   }
@@ -1422,7 +1451,11 @@ rt_status rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_d
   // share a device (several "virtual ranks" on one GPU: tests, rehearsals) or RT_MULTI_PEER_COPIES use peer copies.
   m->self_send = (flags & RT_MULTI_RCCL_SELF) != 0;
   const bool want_rccl = distinct && !(flags & RT_MULTI_PEER_COPIES) && (n > 1 || m->self_send);
-  if (want_rccl) {
+  if (want_rccl && !rccl().ok && !m->self_send) {
+    // no RCCL in this process (librccl.so.1 cannot be loaded): the gather falls back to peer copies, which need nothing but
+    // HIP; rt_multi_uses_rccl() tells the caller which transport a handle got
+    (void)fail(RT_OK, "rt_multi_create: " + rccl().error + " — gathering with peer copies");
+  } else if (want_rccl) {
     if (!rccl().ok)
       return bail(fail(RT_ERR_HIP, "rt_multi_create: " + rccl().error));
     m->comms.assign(n, nullptr);
@@ -1437,8 +1470,11 @@ rt_status rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_d
 int rt_multi_rank_count(const rt_multi *m) { return m ? static_cast<int>(m->devices.size()) : 0; }
 int rt_multi_uses_rccl(const rt_multi *m) { return m && !m->comms.empty() ? 1 : 0; }
 
-rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device0, rt_stats *stats,
-                          rt_multi_timing *timing) {
+} // extern "C"
+
+namespace {
+rt_status multi_render_impl(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device0, rt_stats *stats,
+                            rt_multi_timing *timing, int n_reports, rt_progress_fn progress, void *user) {
   if (!m || !cam || !cfg || !rgb_out_device0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render: NULL argument");
   if (rt_status st = check_cfg(cfg))
@@ -1449,6 +1485,9 @@ rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg
   const size_t row_floats = static_cast<size_t>(cfg->width) * 3;
   std::vector<int> rows(static_cast<size_t>(n));
   std::vector<LaunchInfo> info(static_cast<size_t>(n));
+  // progress between the first and the last report exists in path mode only (its kernels take samples from a queue whose
+  // head is counters[0]); the other modes' frames take milliseconds and report once, at the end
+  const bool poll = progress && n_reports > 1 && cfg->mode == RT_MODE_PATH;
   // 1. every rank renders its rows (row r, r + n, r + 2n, ...) into its compact band buffer; launches are asynchronous,
   //    so one host thread keeps all devices busy
   for (int r = 0; r < n; ++r) {
@@ -1462,6 +1501,8 @@ rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg
     band.band_rows = 1, band.band_stride = n, band.band_offset = r, band.n_local_rows = rows[r];
     Workspace ws;
     ws.info = &info[r];
+    if (poll) // the queue head the poll reads must not be the previous frame's
+      RT_HIP(hipMemset(m->scenes[r]->counters, 0, sizeof(unsigned long long)));
     RT_HIP(hipEventRecord(m->begun[r], m->streams[r]));
     if (rt_status st = render_impl(m->scenes[r], cam, &band, static_cast<float *>(m->bands[r].ptr), m->streams[r], nullptr, ws))
       return st;
@@ -1476,16 +1517,32 @@ rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg
     if (rows[r])
       if (rt_status st = ensure(m->landing[r], static_cast<size_t>(rows[r]) * row_floats * sizeof(float)))
         return st;
+  // device 0's stream waits for every rank's render before the gather starts, so that the two events around the gather
+  // time the transfer and the placement alone (the bands are <= 12 MB per peer: nothing is lost by not overlapping them)
+  for (int r = 0; r < n; ++r)
+    if (rows[r])
+      RT_HIP(hipStreamWaitEvent(s0, m->done[r], 0));
+  RT_HIP(hipEventRecord(m->gather_begin, s0));
   if (use_rccl) {
     RT_NCCL(rccl().GroupStart());
-    for (int r = first_moved; r < n; ++r) {
+    int first_error = 0; // a failed call must not leave this thread's RCCL group open (later RCCL calls — PyTorch's too — would queue into it)
+    const char *failed = "";
+    for (int r = first_moved; r < n && !first_error; ++r) {
       if (!rows[r])
         continue;
       const size_t count = static_cast<size_t>(rows[r]) * row_floats;
-      RT_NCCL(rccl().Send(m->bands[r].ptr, count, Rccl::Float32, 0, m->comms[r], m->streams[r])); // ordered after rank r's render
-      RT_NCCL(rccl().Recv(m->landing[r].ptr, count, Rccl::Float32, r, m->comms[0], s0));
+      if ((first_error = rccl().Send(m->bands[r].ptr, count, Rccl::Float32, 0, m->comms[r], m->streams[r])) != 0) { // ordered after rank r's render
+        failed = "ncclSend";
+        break;
+      }
+      if ((first_error = rccl().Recv(m->landing[r].ptr, count, Rccl::Float32, r, m->comms[0], s0)) != 0)
+        failed = "ncclRecv";
     }
-    RT_NCCL(rccl().GroupEnd());
+    const int end_error = rccl().GroupEnd();
+    if (first_error)
+      return fail(RT_ERR_HIP, std::string(failed) + ": " + rccl().GetErrorString(first_error));
+    if (end_error)
+      return fail(RT_ERR_HIP, std::string("ncclGroupEnd: ") + rccl().GetErrorString(end_error));
   } else {
     for (int r = 1; r < n; ++r) {
       if (!rows[r])
@@ -1509,17 +1566,56 @@ rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg
     }
     RT_HIP(hipGetLastError());
   }
-  // 3. the frame is complete when rank 0's stream is idle; the other streams only have their sends left
-  for (int r = 0; r < n; ++r)
-    if (rows[r])
-      RT_HIP(hipEventSynchronize(m->done[r]));
-  const auto all_rendered = std::chrono::steady_clock::now();
+  RT_HIP(hipEventRecord(m->gather_end, s0));
+  // 3. progress while the ranks render: the share of the frame's samples their queues have handed out
+  if (poll) {
+    uint64_t total = 0;
+    for (int r = 0; r < n; ++r)
+      total += rows[r] ? info[r].n_samples : 0;
+    int reported = 0;
+    for (;;) {
+      bool all_done = true;
+      unsigned long long handed = 0;
+      for (int r = 0; r < n; ++r) {
+        if (!rows[r])
+          continue;
+        const hipError_t q = hipEventQuery(m->done[r]);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(RT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        if (q == hipErrorNotReady) {
+          all_done = false;
+          RT_ON_DEVICE(m->devices[r]);
+          unsigned long long head = 0;
+          RT_HIP(hipMemcpyAsync(&head, info[r].counters, sizeof head, hipMemcpyDeviceToHost, m->poll_streams[r]));
+          RT_HIP(hipStreamSynchronize(m->poll_streams[r]));
+          handed += std::min<unsigned long long>(head, info[r].n_samples);
+        } else {
+          handed += info[r].n_samples;
+        }
+      }
+      (void)hipGetLastError(); // hipErrorNotReady is not an error
+      if (all_done)
+        break;
+      const int due = static_cast<int>(handed * static_cast<unsigned long long>(n_reports) / std::max<uint64_t>(total, 1));
+      while (reported < std::min(due, n_reports - 1)) // the last report is the finished frame's
+        progress(static_cast<float>(++reported) / static_cast<float>(n_reports), user);
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  // 4. the frame is complete when rank 0's stream is idle; the other streams only have their sends left
   for (int r = n - 1; r >= 0; --r) {
     RT_ON_DEVICE(m->devices[r]);
     RT_HIP(hipStreamSynchronize(m->streams[r]));
   }
-  // what the gather adds to the frame: from the moment the last rank finished rendering to the assembled frame
-  const float gather_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - all_rendered).count();
+  if (progress)
+    progress(1.f, user);
+  // what the gather adds to the frame: transfer + placement, HIP events on device 0's stream around them (the stream waits
+  // for every rank's render first)
+  float gather_ms = 0.f;
+  {
+    RT_ON_DEVICE(m->devices[0]);
+    RT_HIP(hipEventElapsedTime(&gather_ms, m->gather_begin, m->gather_end));
+  }
   if (stats || timing) {
     if (stats)
       std::memset(stats, 0, sizeof *stats);
@@ -1551,21 +1647,34 @@ rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg
   }
   return RT_OK;
 }
+} // namespace
 
-rt_status rt_multi_render_host(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, rt_stats *stats,
-                               rt_multi_timing *timing) {
+extern "C" {
+
+rt_status rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_device0, rt_stats *stats,
+                          rt_multi_timing *timing) {
+  return multi_render_impl(m, cam, cfg, rgb_out_device0, stats, timing, 0, nullptr, nullptr);
+}
+
+rt_status rt_multi_render_frame_host(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, int n_reports,
+                                     rt_progress_fn progress, void *user, rt_stats *stats, rt_multi_timing *timing) {
   if (!m || !cfg || !rgb_out_host)
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_host: NULL argument");
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_frame_host: NULL argument");
   if (rt_status st = check_cfg(cfg))
     return st;
   RT_ON_DEVICE(m->devices[0]);
   const size_t bytes = static_cast<size_t>(cfg->height) * cfg->width * 3 * sizeof(float);
   if (rt_status st = ensure(m->frame, bytes))
     return st;
-  if (rt_status st = rt_multi_render(m, cam, cfg, static_cast<float *>(m->frame.ptr), stats, timing))
+  if (rt_status st = multi_render_impl(m, cam, cfg, static_cast<float *>(m->frame.ptr), stats, timing, std::clamp(n_reports, 1, 256), progress, user))
     return st;
   RT_HIP(hipMemcpy(rgb_out_host, m->frame.ptr, bytes, hipMemcpyDeviceToHost));
   return RT_OK;
+}
+
+rt_status rt_multi_render_host(rt_multi *m, const rt_camera *cam, const rt_render_cfg *cfg, float *rgb_out_host, rt_stats *stats,
+                               rt_multi_timing *timing) {
+  return rt_multi_render_frame_host(m, cam, cfg, rgb_out_host, 1, nullptr, nullptr, stats, timing);
 }
 
 rt_status rt_trace_rays(rt_scene *sc, const rt_ray *rays, size_t n, rt_hit *hits) {

@@ -58,7 +58,13 @@ public:
   std::shared_ptr<Camera> camera;
   int samples_per_pixel_edge;
   int device = 0;            ///< the GPU of a single-device render
-  bool all_devices = true;   ///< more than one GPU visible: deal the frame's rows to all of them (rt_multi_*, RCCL gather)
+  /// Opt in: deal the frame's rows to every visible GPU (rt_multi_*, gather over RCCL, or peer copies where RCCL cannot be
+  /// loaded).  Off by default: that transport is covered by virtual ranks and a one-rank RCCL self-send on one-GPU boxes only
+  /// (DESIGN.md 8), and frames of a few milliseconds (the deterministic modes) gain nothing from a gather.
+  bool all_devices = false;
+  /// Explicit ranks instead of "every visible GPU" (wins over all_devices when not empty).  A device may be listed more than
+  /// once (several ranks on one GPU, bands moved by device copies): that is how the one-GPU tests drive this route.
+  std::vector<int> rank_devices;
   rt_stats last_stats{};
   rt_multi_timing last_timing{}; ///< multi-GPU renders: per-rank kernel time and the gather
 
@@ -80,20 +86,21 @@ public:
   /// arrays change (an animation changes the camera, not the World), and the frame lives in a device buffer the
   /// library reuses.  One GPU: the image is rendered as `progress_slices` horizontal slices queued back to back, the
   /// callback is invoked with rows_done / height as each finishes (the reference reports once per column), and one
-  /// device-to-host copy fills HdrImage::pixels.  Several GPUs: the rows are dealt round-robin to all of them and
-  /// gathered over RCCL; progress is reported once, at the end.
+  /// device-to-host copy fills HdrImage::pixels.  Several GPUs (all_devices): the rows are dealt round-robin to all of them
+  /// and gathered to the first; progress is the share of the frame's samples the devices' queues have handed out.
   void fire_all_rays(const World &world, const GpuRenderMode &mode, ProgressCallback report_progress = [](float) {},
                      int progress_slices = 8) {
     FlatScene flat = flatten_world(world);
-    const bool want_multi = all_devices && rt_device_count() > 1;
-    if (!(scene_ || multi_) || want_multi != (multi_ != nullptr) || !flat.same_bits(resident_)) {
+    const bool want_multi = !rank_devices.empty() || (all_devices && rt_device_count() > 1);
+    if (!(scene_ || multi_) || want_multi != (multi_ != nullptr) || rank_devices != resident_ranks_ || !flat.same_bits(resident_)) {
       release();
       rt_scene_desc desc = flat.desc();
       if (want_multi)
-        check(rt_multi_create(&desc, nullptr, 0, 0, &multi_));
+        check(rt_multi_create(&desc, rank_devices.empty() ? nullptr : rank_devices.data(), static_cast<int>(rank_devices.size()), 0, &multi_));
       else
         check(rt_scene_create(&desc, device, &scene_));
       resident_ = std::move(flat);
+      resident_ranks_ = rank_devices;
     }
     const rt_camera cam = flatten_camera(*camera);
     rt_render_cfg cfg{};
@@ -112,8 +119,8 @@ public:
     last_stats = rt_stats{};
     last_timing = rt_multi_timing{};
     if (multi_) {
-      check(rt_multi_render_host(multi_, &cam, &cfg, pixels, &last_stats, &last_timing));
-      report_progress(1.f);
+      auto trampoline = [](float fraction, void *user) { (*static_cast<ProgressCallback *>(user))(fraction); };
+      check(rt_multi_render_frame_host(multi_, &cam, &cfg, pixels, progress_slices, trampoline, &report_progress, &last_stats, &last_timing));
     } else {
       auto trampoline = [](float fraction, void *user) { (*static_cast<ProgressCallback *>(user))(fraction); };
       check(rt_render_frame_host(scene_, &cam, &cfg, pixels, progress_slices, trampoline, &report_progress, &last_stats));
@@ -133,6 +140,7 @@ private:
   rt_scene *scene_ = nullptr;
   rt_multi *multi_ = nullptr;
   FlatScene resident_; // what the handle above was created from
+  std::vector<int> resident_ranks_;
 
   static void check(rt_status rc) {
     if (rc != RT_OK)

@@ -6,7 +6,10 @@
 //   raytracer_gpu <scene.txt> -o out.pfm [--mode onoff|flat|pointlight|path] [--width W] [--height H]
 //                 [--aa N] [--n_rays N] [--roulette N] [--max-depth N] [--seq N] [--bvh] [--define name=value]...
 //                 [--repeat N]   render the frame N more times on the resident World and report the best end-to-end time
-//                 [--one-gpu]    do not spread the frame over the visible GPUs
+//                 [--all-gpus]   spread the frame's rows over every visible GPU (rt_multi_*; opt-in, GpuImageTracer::all_devices)
+//                 [--ranks a,b,..] explicit ranks for the multi-GPU route (a device may repeat: the one-GPU test box lists 0,0,0)
+//                 [--progress]   print the callback's fractions to stderr
+//                 [--one-gpu]    accepted and ignored: one GPU is the default
 #include "colors.hpp"
 #include "geometry.hpp"
 #include "renderers.hpp"
@@ -18,6 +21,7 @@
 #include <chrono>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 
 int main(int argc, char **argv) {
   if (argc < 2) {
@@ -27,8 +31,10 @@ int main(int argc, char **argv) {
   std::string scene_file = argv[1], out, mode = "flat";
   int width = 1280, height = 960, aa = 1, n_rays = 10, roulette = 3, max_depth = 5;
   uint64_t seq = 54;
-  bool bvh = false, one_gpu = false;
+  bool bvh = false, all_gpus = false;
   int repeat = 0;
+  bool show_progress = false;
+  std::vector<int> ranks;
   std::unordered_map<std::string, float> defines;
   for (int i = 2; i < argc; ++i) {
     std::string s = argv[i];
@@ -49,8 +55,15 @@ int main(int argc, char **argv) {
     else if (s == "--max-depth") max_depth = std::stoi(next());
     else if (s == "--seq") seq = std::stoull(next());
     else if (s == "--bvh") bvh = true;
-    else if (s == "--one-gpu") one_gpu = true;
+    else if (s == "--one-gpu") all_gpus = false;
+    else if (s == "--all-gpus") all_gpus = true;
     else if (s == "--repeat") repeat = std::stoi(next());
+    else if (s == "--progress") show_progress = true;
+    else if (s == "--ranks") {
+      std::stringstream list{next()};
+      for (std::string item; std::getline(list, item, ',');)
+        ranks.push_back(std::stoi(item));
+    }
     else if (s == "--define") {
       std::string d = next();
       auto eq = d.find('=');
@@ -91,9 +104,13 @@ int main(int argc, char **argv) {
     if (bvh)
       m.flags |= RT_FLAG_ACCEL_BVH;
 
-    tracer.all_devices = !one_gpu;
+    tracer.all_devices = all_gpus;
+    tracer.rank_devices = ranks;
     auto t0 = std::chrono::steady_clock::now();
-    tracer.fire_all_rays(scene.world, m);
+    if (show_progress)
+      tracer.fire_all_rays(scene.world, m, [](float fraction) { std::cerr << "progress " << fraction << '\n'; });
+    else
+      tracer.fire_all_rays(scene.world, m);
     auto t1 = std::chrono::steady_clock::now();
     // the first call pays for the HIP runtime, the code object and the upload of the World; later frames (an animation,
     // a resident service) do not: --repeat times fire_all_rays alone, World already in HBM

@@ -220,13 +220,20 @@ class GpuImageTracer:
         return out
 
 
-    def fire_all_rays_multi(self, world: MultiDeviceWorld, mode: RenderMode, out=None):
+    def fire_all_rays_multi(self, world: MultiDeviceWorld, mode: RenderMode, out=None, progress=None, n_reports: int = 8):
         """The whole frame on every device of `world`.  out=None -> numpy [H, W, 3]; out=<tensor on the first device> stays
-        in HBM.  Sets last_stats (summed over ranks) and last_timing (abi.rt_multi_timing)."""
+        in HBM.  Sets last_stats (summed over ranks) and last_timing (abi.rt_multi_timing).  progress (host output only):
+        the reference's callback, called up to n_reports times with the finished fraction of the frame's samples over all
+        ranks (rt_multi_render_frame_host)."""
         cfg = self.make_cfg(mode)
         cam = self.camera.to_abi()
         stats, timing = abi.rt_stats(), abi.rt_multi_timing()
-        if out is None:
+        if out is None and progress is not None:
+            img = np.empty((self.height, self.width, 3), dtype=np.float32)
+            cb = C.CFUNCTYPE(None, C.c_float, C.c_void_p)(lambda f, _u: progress(f))
+            check(dll().rt_multi_render_frame_host(world.handle, C.byref(cam), C.byref(cfg), img.ctypes.data, n_reports,
+                                                   C.cast(cb, C.c_void_p), None, C.byref(stats), C.byref(timing)))
+        elif out is None:
             img = np.empty((self.height, self.width, 3), dtype=np.float32)
             check(dll().rt_multi_render_host(world.handle, C.byref(cam), C.byref(cfg), img.ctypes.data, C.byref(stats), C.byref(timing)))
         else:

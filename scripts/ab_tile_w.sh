@@ -1,5 +1,7 @@
 #!/bin/bash
 # waves per workgroup of the tile kernel (RT_TILE_W) on N = 4096 (68-row slice), 1024 and 512
+# The RT_* environment knobs exist only in -DRT_TUNING builds:  scripts/build_variant.sh tuning -DRT_TUNING, then
+# RAYTRACER_AMD_LIB=$PWD/raytracer_amd/csrc/build/variants/tuning/libraytracer_amd.so <this script> (the shipped library ignores them).
 for spec in "4096 68" "1024 270" "512 1080"; do
   set -- $spec
   for w in 1 2 4 8; do

@@ -157,3 +157,27 @@ def test_cpp_route_resident_world_and_repeat(tmp_path):
     assert np.array_equal(once, again) and info1["rays"] == info2["rays"]
     assert 0 < info2["resident_frame_ms"] < 1e3 * info2["elapsed_s"]
     assert info2["kernel"].startswith("k_render_path_wave") and info2["gpus"] == 1
+
+
+@needs_bin
+@pytest.mark.gpu
+def test_cpp_route_over_several_ranks_with_progress(tmp_path):
+    """GpuImageTracer's multi-GPU route (rank_devices / all_devices -> rt_multi_render_frame_host) on the one-GPU box: three
+    ranks on device 0.  Same PFM bytes and ray count as the single-device route; the progress callback's fractions increase
+    and end at 1."""
+    args = ("--mode", "path", "--width", 120, "--height", 70, "--aa", 2, "--n_rays", 4, "--roulette", 2, "--max-depth", 4, "--seq", 11)
+    one, info1 = run_gpu_bin(tmp_path, SCENE_TEXT, *args)
+    txt = tmp_path / "multi.txt"
+    txt.write_text(SCENE_TEXT)
+    out = tmp_path / "multi.pfm"
+    res = subprocess.run([GPU_BIN, str(txt), "-o", str(out), *map(str, args), "--ranks", "0,0,0", "--progress"], capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    info3 = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info3["gpus"] == 3 and info3["rays"] == info1["rays"]
+    assert np.array_equal(O.read_pfm(out), one)
+    seen = [float(line.split()[1]) for line in res.stderr.splitlines() if line.startswith("progress ")]
+    assert seen and seen == sorted(set(seen)) and seen[-1] == 1.0 and seen[0] > 0
+    # --all-gpus on a box with one GPU is the single-device route
+    same, info = run_gpu_bin(tmp_path, SCENE_TEXT, *args, "--all-gpus")
+    assert np.array_equal(same, one) and info["gpus"] == 1

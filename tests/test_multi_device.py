@@ -111,3 +111,29 @@ def test_frame_host_slices_and_progress(scenes):
         assert np.array_equal(tr.fire_all_rays_host(world, mode), want)  # no callback: one launch
         assert int(tr.last_stats.rays) == rays
     world.close()
+
+
+@pytest.mark.parametrize("devices,rccl_self", [([0], False), ([0, 0, 0], False), ([0], True)])
+def test_multi_frame_host_progress(scenes, devices, rccl_self):
+    """rt_multi_render_frame_host: the multi-device frame with the reference's progress callback.  Same pixels and ray
+    count as the single call; reports increase, lie in (0, 1] and end at exactly 1; gather_ms is a HIP-event duration."""
+    scene = scenes["demo_path"]
+    single = DeviceWorld(scene)
+    tr = GpuImageTracer(120, 80, scene.camera, 2)
+    multi = MultiDeviceWorld(scene, devices, rccl_self=rccl_self)
+    for mode in (RenderMode("path", **PATH), RenderMode("pointlight")):
+        want = tr.fire_all_rays(single, mode)
+        rays = int(tr.last_stats.rays)
+        seen = []
+        got = tr.fire_all_rays_multi(multi, mode, progress=seen.append, n_reports=6)
+        assert np.array_equal(got, want), (mode.mode, devices)
+        assert int(tr.last_stats.rays) == rays
+        assert 1 <= len(seen) <= 6 and seen == sorted(set(seen)) and seen[0] > 0 and seen[-1] == 1.0
+        t = tr.last_timing
+        assert t.n_ranks == len(devices) and sum(t.rays[: len(devices)]) == rays and 0 <= t.gather_ms < 1000
+        # the counters' head is cleared per frame: a second frame reports from the start again
+        seen2 = []
+        assert np.array_equal(tr.fire_all_rays_multi(multi, mode, progress=seen2.append, n_reports=6), want)
+        assert seen2 and seen2[-1] == 1.0 and seen2 == sorted(set(seen2))
+    multi.close()
+    single.close()

@@ -74,7 +74,7 @@ def test_noalloc_rejects_what_does_not_fit(scenes):
     # sample buffer alone: 3840 * 2160 * 16 * 12 bytes = 1.6 GB
     st, msg, _, _ = _render("rt_render_noalloc", world, GpuImageTracer(3840, 2160, cam, 4), RenderMode("flat"))
     assert st == abi.RT_ERR_INVALID_ARGUMENT and "sample buffer" in msg and str(abi.RT_NOALLOC_SCRATCH_BYTES) in msg
-    # node stacks: depth 64 x 256 lanes x 52 bytes = 852 KB per workgroup, one per CU does not fit
+    # node stacks: depth 64 x 256 lanes x 64 bytes (a 16-word node record) = 1 MiB per workgroup, one per CU does not fit
     st, msg, _, _ = _render("rt_render_noalloc", world, GpuImageTracer(256, 256, cam, 1), RenderMode("path", n_rays=2, max_depth=64))
     assert st == abi.RT_ERR_INVALID_ARGUMENT and "node stacks" in msg
     _pair(world, GpuImageTracer(40, 30, cam, 2), RenderMode("path", n_rays=3, roulette=2, max_depth=3))
