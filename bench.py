@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 # MI355X fp32 peak, vector and matrix alike (v_mfma_f32_32x32x2_f32 runs on the VALU's fp32 lanes): 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 # (MI355X_MICROARCH.md: 157.3 TF spec for both, 155 measured on the MFMA)
 FP32_VALU_PEAK_TFLOPS = 157.3
+# dense bf16 MFMA peak: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz (v_mfma_f32_32x32x16_bf16 = 32768 flops in 32 cycles; the guide's "~2.5 PF dense")
+BF16_MFMA_PEAK_TFLOPS = 256 * 4 * 1024 * 2.4e9 / 1e12
 
 # fp32 flops one object test costs (FMA = 2, everything else 1), by the arithmetic form a kernel uses:
 #   world-space sphere filter (wide ISO register rows, rt_wide.h): b = O.u - C.u (3 fma = 6), c = (O.O + k) - 2 O.C (1 add + 3 fma = 7),
@@ -50,6 +52,11 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 #   the same filter on the matrix cores (rt_tile.h): four v_mfma_f32_32x32x2_f32 per 32 rays x 32 spheres = 4 x 4096 / 1024 = 16 flops per
 #     test (K = 4 for b and for c: the constant terms 1 * O.u and k * 1 are multiply-adds too) + the VALU's d = b^2 - c (2): 18
 F_SPHERE_TILE = 18.0
+#   round 3, the same two products on the bf16 matrix cores (rt_tile.h, kernel name "...,BF16x3>"): every binary32 operand split into
+#     three bf16 parts, six partial products per term -> 24 of the 32 K slots of two v_mfma_f32_32x32x16_bf16 per product: four MFMAs
+#     per 32 x 32 tile = 4 x 32768 / 1024 = 128 bf16-MFMA flops per test (96 of them in slots that hold data), priced against the
+#     bf16 dense peak; the VALU still does d = b^2 - c (2 fp32 flops per test) and everything else of the ray
+F_SPHERE_TILE_BF16_MFMA = 128.0
 F_SPHERE_WORLD, F_SPHERE_OBJECT, F_SPHERE_WRITTEN = 15.0, 52.0, 52.0
 F_PLANE_FMA, F_PLANE_WRITTEN = 13.0, 35.0
 F_EPILOGUE = 54.0 + 75.0  # the winner's hit record + scatter / shading, same in both counts
@@ -133,6 +140,28 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
     executed, algorithmic = flops_per_ray(census, kernel)
     ach = rays * executed / (kernel_ms * 1e-3) / 1e12
     alg = rays * algorithmic / (kernel_ms * 1e-3) / 1e12
+    if "BF16x3" in kernel:
+        # The dominant unit is the bf16 matrix pipe: `achieved` / `frac` / `frac_executed` count ITS flops against ITS peak.  The fp32
+        # work that stays on the vector ALU (d = b^2 - c per test, the per-lane sphere, planes, hit record, exact record, shading) is
+        # reported beside it against the fp32 peak; `frac_algorithmic` prices the reference's arithmetic as written (52 fp32 flops per
+        # sphere test) against the fp32 vector peak, the unit the reference's own code would run on.
+        n_tests = -(-max(census["spheres"] - 1, 0) // 32) * 32  # register spheres, padded to whole tiles (what the MFMAs multiply)
+        mfma = rays * F_SPHERE_TILE_BF16_MFMA * n_tests / (kernel_ms * 1e-3) / 1e12
+        valu = rays * (executed - (F_SPHERE_TILE - 2.0) * max(census["spheres"] - 1, 0)) / (kernel_ms * 1e-3) / 1e12
+        out = {"bound": "mfma", "peak_kind": "bf16 dense MFMA (256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz); v_mfma_f32_32x32x16_bf16 on 3-way bf16 splits of the binary32 operands, binary32 accumulate",
+               "achieved": mfma, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma / BF16_MFMA_PEAK_TFLOPS,
+               "frac_executed": mfma / BF16_MFMA_PEAK_TFLOPS,
+               "mfma_flops_per_ray": F_SPHERE_TILE_BF16_MFMA * n_tests,
+               "valu_fp32": {"tflops": valu, "peak": FP32_VALU_PEAK_TFLOPS, "frac": valu / FP32_VALU_PEAK_TFLOPS,
+                             "flops_per_ray": executed - (F_SPHERE_TILE - 2.0) * max(census["spheres"] - 1, 0)},
+               "frac_algorithmic": alg / FP32_VALU_PEAK_TFLOPS, "algorithmic_peak_kind": "fp32 vector peak, 157.3 TFLOP/s",
+               "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": alg,
+               "traffic": None, "traffic_source": None, "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms}
+        if profile is not None and "FETCH_SIZE" in profile["counters"] and "WRITE_SIZE" in profile["counters"]:
+            c, launches = profile["counters"], float(profile.get("launches", 1))
+            out["traffic"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
+            out["traffic_source"] = profile["_source"]
+        return out
     out = {"bound": "mfma" if "path_tile<" in kernel else "valu", "peak_kind": "fp32, vector = matrix: v_mfma_f32_32x32x2_f32 runs on the VALU's fp32 lanes (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)",
            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
            "frac_executed": ach / FP32_VALU_PEAK_TFLOPS, "frac_algorithmic": alg / FP32_VALU_PEAK_TFLOPS,
@@ -404,6 +433,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "hit records, shading and scattering in binary32, sample sums in 64-bit fixed point; the large-world sphere FILTER (which "
+                          "only ranks candidates: the winner's record is recomputed as the reference writes it) multiplies binary32 operands split "
+                          "exactly into three bf16 parts on the bf16 matrix cores with binary32 accumulation — measured error 2^-22.4 of sum|terms|, "
+                          "the binary32 fma chain's 2^-22.6 (scripts/microbench/bf16_probe.hip)",
             "config": {"workload": (f"samples/{args.scene} (reference sample scene)" if args.scene else
                                     f"synthetic {args.spheres}-random-sphere + floor + sky scene") + f", --mode path, "
                                    f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "

@@ -404,7 +404,8 @@ rt_status check_cfg(const rt_render_cfg *cfg) {
 // separate translation units so that the ~30 kernels compile in parallel).
 const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
-const void *rt_tile_kernel(int waves, bool csg); // rt_wide_tile.hip: k_render_path_tile<8, W, CSG>
+const void *rt_tile_kernel(int waves, bool csg); // rt_wide_tile.hip: k_render_path_tile<S, W, CSG>
+int rt_tile_s();                                // its S: sphere tiles per wave and pass
 // From how many register spheres on the large-world kernels replace the per-lane scan of the small-world kernel.  Measured
 // with the tile kernel (synthetic worlds, 960x540 AA=4, frame ms tile | per-lane): 16 spheres 17.2 | 9.8, 24: 20.5 | 19.2,
 // 32: 26.6 | 27.5, 48: 26.2 | 27.5, 64: 25.7 | 26.6 — one full tile of 32 is the break-even.
@@ -651,7 +652,53 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     }
   std::vector<float> wide_tiles; // rt_tile.h: the MFMA's A operands
   const size_t n_wide_tiles = all_iso ? (wide_recs.size() + 31) / 32 : 0;
-  wide_tiles.resize(n_wide_tiles * 192);
+  wide_tiles.resize(n_wide_tiles * rtd::RT_TILE_WORDS);
+#if RT_TILE_BF16
+  // K slot s of the two 16-slot chunks (rt_tile.h): 6 t + j, t = x y z: part {0 0 0 1 1 2}[j] of the coordinate; 18-20: 1;
+  // 21-23: the parts of k; 24-31: 0.  Lane l of chunk c holds slots 16 c + 8 (l / 32) + 0..7 of sphere l % 32 as four words.
+  auto bf16_rn = [](float x) -> uint32_t { // round to nearest even (finite values)
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  auto bf16_value = [](uint32_t h) {
+    const uint32_t u = h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  auto split3 = [&](float x, uint32_t part[3]) { // x = part0 + part1 + part2 exactly (8 + 8 + 8 significant bits)
+    part[0] = bf16_rn(x);
+    float r = x - bf16_value(part[0]);
+    part[1] = bf16_rn(r);
+    r -= bf16_value(part[1]);
+    part[2] = bf16_rn(r);
+  };
+  static const int part_of_slot[6] = {0, 0, 0, 1, 1, 2};
+  for (size_t t = 0; t < n_wide_tiles; ++t)
+    for (size_t i = 0; i < 32; ++i) {
+      const size_t k = t * 32 + i;
+      const bool valid = k < wide_recs.size();
+      const float v[4] = {valid ? wide_iso[4 * k] : 0.f, valid ? wide_iso[4 * k + 1] : 0.f, valid ? wide_iso[4 * k + 2] : 0.f,
+                          valid ? wide_iso[4 * k + 3] : 1e30f}; // a place past the last sphere: c = 1e30, never hit
+      uint32_t parts[4][3];
+      for (int q = 0; q < 4; ++q)
+        split3(v[q], parts[q]);
+      uint32_t slot[32] = {0};
+      for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < 6; ++j)
+          slot[6 * q + j] = parts[q][part_of_slot[j]];
+      slot[18] = slot[19] = slot[20] = 0x3f80u; // 1
+      slot[21] = parts[3][0], slot[22] = parts[3][1], slot[23] = parts[3][2];
+      for (size_t c = 0; c < 2; ++c)
+        for (size_t half = 0; half < 2; ++half)
+          for (size_t w = 0; w < 4; ++w) {
+            const size_t s0 = 16 * c + 8 * half + 2 * w;
+            const uint32_t word = slot[s0] | (slot[s0 + 1] << 16);
+            std::memcpy(&wide_tiles[t * rtd::RT_TILE_WORDS + (c * 64 + half * 32 + i) * 4 + w], &word, 4);
+          }
+    }
+#else
   for (size_t t = 0; t < n_wide_tiles; ++t)
     for (size_t l = 0; l < 64; ++l) {
       const size_t k = t * 32 + l % 32;
@@ -662,6 +709,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       wide_tiles[t * 192 + 64 + l] = upper ? 1.f : cz;
       wide_tiles[t * 192 + 128 + l] = upper ? kk : cz;
     }
+#endif
   std::vector<int32_t> shape_origin(4 * static_cast<size_t>(d->n_shapes), -1);
   for (uint32_t i = 0; i < d->n_shapes; ++i)
     shape_origin[4 * static_cast<size_t>(i) + 3] = 0;
@@ -1025,15 +1073,16 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
 #else
         constexpr int w_env = 0;
 #endif
+        const int tile_s = rt_tile_s();
         waves = 1;
-        while (waves < 4 && tiles > waves * 16)
+        while (waves < 4 && tiles > waves * 2 * tile_s) // up to two passes per wave count
           waves *= 2;
         if (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8)
           waves = w_env;
         block = 64u * static_cast<unsigned>(waves);
         path_kernel = rt_tile_kernel(waves, sc->dev.n_csg_tops > 0);
         nodes_per_level = 64, stacks_per_block = waves, node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave (rt_wavepath.h)
-        std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=8,W=%d>", waves);
+        std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=%d,W=%d%s>", tile_s, waves, RT_TILE_BF16 ? ",BF16x3" : "");
       }
     }
     int per_cu = 0;

@@ -69,15 +69,98 @@ struct alignas(16) TileRay {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The same two products on the bf16 matrix cores (round 3; RT_TILE_BF16, the default build).
+// v_mfma_f32_32x32x16_bf16 multiplies 16 K slots in 8 passes (32 cycles) where the binary32 instruction takes 16 passes for 2.
+// Every binary32 operand is split into three bf16 parts, x = x0 + x1 + x2 EXACTLY (round to nearest: 8 + 8 + 8 significant
+// bits), and a term x y of the inner product becomes the six partial products x0 y0 + x0 y1 + x0 y2 + x1 y0 + x1 y1 + x2 y0 —
+// each exact in the binary32 accumulator; what is dropped (x1 y2, x2 y1, x2 y2) is below 2^-24 of the term.  Measured on the
+// device (scripts/microbench/bf16_probe.hip, 200 k products of filter-like data): |error| <= 2^-22.4 of sum |terms| against
+// 2^-22.6 for the binary32 fmaf chain — the same accuracy, which world_filter_ok (rt_api.hip) already prices.
+// K slots (32 = two MFMAs per product; the A operand is the SAME for b and c):
+//     slot 6 t + j, t = x y z:  A = part {0 0 0 1 1 2}[j] of c_t,   B_b = part {0 1 2 0 1 0}[j] of -u_t,   B_c = the same of -2 o_t
+//     slots 18-20:              A = 1,                             B_b = the parts of O.u,               B_c = 0
+//     slots 21-23:              A = the parts of k,                B_b = 0,                              B_c = 1
+//     slots 24-31:              0
+// Lane l supplies slots 8 (l / 32) + 0..7 of a 16-slot chunk for row / column l % 32 as four words of bf16 pairs; the result
+// registers are laid out as the binary32 shape's (probed), so everything after the products is shared with it.
+// Rate (same probe, 4 waves per SIMD): 163 SIMD-cycles per 32 x 32 tile with the 24 VALU instructions of the filter against
+// 352 for the binary32 MFMAs, and 139 for the four bf16 MFMAs alone — unlike the binary32 MFMA, which runs on the VALU's
+// fp32 lanes, the bf16 matrix pipe overlaps with the vector instructions of the other waves.
+// Cost: 8 sphere registers per tile instead of 3, and a 128-byte ray record in LDS, which limits a CU to 12 waves (3 per SIMD,
+// 168 VGPRs each).  Measured (Mrays/s; N=512 1080p AA=4 at W = 1 | N=4096 480x136 AA=4 at W = 4; scripts/ab_tile_bf16.sh):
+//     binary32 MFMAs, S = 8, 4 waves per SIMD   10 787 |  1 352
+//     bf16, S = 4, 3 waves per SIMD             13 011 |  2 030
+//     bf16, S = 8, 3 waves per SIMD (17 spilled) 13 973 |  2 165      <- the build
+//     bf16, S = 8 / 16, 2 waves per SIMD        10 994 / 11 381 | 1 772 / 1 871   (the pipes overlap ACROSS waves: fewer waves, less overlap)
+// Phase split per wave iteration at N=4096, W=4 (-DRT_PROFILE_PHASES): queue 7.2 k, filter 147 k (308 k with binary32 MFMAs),
+// finish + shade 9.7 k cycles; N=512, W=1: 4.1 k / 19.6 k / 9.1 k.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = p[0] + p[1] + p[2] exactly; parts as bf16 bit patterns
+RT_DEV inline void bf16_split3(float x, uint32_t p[3]) {
+  const auto rn = [](float v) { // round to nearest even; finite values
+    const uint32_t u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  p[0] = rn(x);
+  float r = x - __uint_as_float(p[0] << 16);
+  p[1] = rn(r);
+  r -= __uint_as_float(p[1] << 16);
+  p[2] = rn(r);
+}
+
+// LDS image of one queued ray, eight quads: 0-2 the 24 slots of B_b, 3-5 of B_c (lanes 0-31 read quads 0 | 3 for the first chunk
+// and 2 | 5 for the second, lanes 32-63 quads 1 | 4 and — their slots 24-31 being zero on the sphere side — anything finite),
+// 6 and 7 what the lane needs around the products.
+struct alignas(16) TileRayBf {
+  uint32_t b[12], c[12];
+  float oo, tmin_u, inv_len; // O.O; tmin as a distance; 1 / |D|
+  int self;                  // position among the register spheres of the sphere the ray leaves (-1: none)
+  float ox, oy, oz, tmin;    // the lane does not carry them across the scan
+  RT_DEV static void pack(const uint32_t (&x)[3], const uint32_t (&y)[3], const uint32_t (&z)[3], uint32_t *w) {
+    w[0] = x[0] | (x[1] << 16), w[1] = x[2] | (x[0] << 16), w[2] = x[1] | (x[0] << 16);
+    w[3] = y[0] | (y[1] << 16), w[4] = y[2] | (y[0] << 16), w[5] = y[1] | (y[0] << 16);
+    w[6] = z[0] | (z[1] << 16), w[7] = z[2] | (z[0] << 16), w[8] = z[1] | (z[0] << 16);
+  }
+  RT_DEV static TileRayBf make(const Ray &ray, int self) {
+    TileRayBf r;
+    const float a = fmaf(ray.d.x, ray.d.x, fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
+    r.inv_len = __builtin_amdgcn_rsqf(a);
+    const float ux = ray.d.x * r.inv_len, uy = ray.d.y * r.inv_len, uz = ray.d.z * r.inv_len;
+    const float ou = fmaf(ray.o.x, ux, fmaf(ray.o.y, uy, ray.o.z * uz));
+    uint32_t px[3], py[3], pz[3], pk[3];
+    bf16_split3(-ux, px), bf16_split3(-uy, py), bf16_split3(-uz, pz), bf16_split3(ou, pk);
+    pack(px, py, pz, r.b);
+    r.b[9] = pk[0] | (pk[1] << 16), r.b[10] = pk[2], r.b[11] = 0u;
+    bf16_split3(-2.f * ray.o.x, px), bf16_split3(-2.f * ray.o.y, py), bf16_split3(-2.f * ray.o.z, pz);
+    pack(px, py, pz, r.c);
+    r.c[9] = 0u, r.c[10] = 0x3f80u << 16, r.c[11] = 0x3f80u | (0x3f80u << 16);
+    r.oo = fmaf(ray.o.x, ray.o.x, fmaf(ray.o.y, ray.o.y, ray.o.z * ray.o.z));
+    r.tmin_u = ray.tmin * a * r.inv_len;
+    r.self = self;
+    r.ox = ray.o.x, r.oy = ray.o.y, r.oz = ray.o.z, r.tmin = ray.tmin;
+    return r;
+  }
+  RT_DEV void restore(Ray &ray) const {
+    ray.o = mk3(ox, oy, oz);
+    ray.tmin = tmin;
+  }
+};
+static_assert(sizeof(TileRayBf) == 128, "eight quads");
+
 #ifndef RT_TILE_OCC
-#define RT_TILE_OCC 4
+#define RT_TILE_OCC (RT_TILE_BF16 ? 3 : 4)
 #endif
 // CSG = false: for worlds without CSG objects, compiled without the evaluators (N=512: +1.3 %; nothing at W = 4, where the
 // scan is 97 % of the time — only the one-wave shape is instantiated that way).
-template <int S, int W, bool CSG = true>
+template <int S, int W, bool CSG = true, bool BF = (RT_TILE_BF16 != 0)>
 __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene s, RenderParams p) {
   constexpr int T = 64 * W;
-  __shared__ TileRay q_ray[T];
+  using QRay = std::conditional_t<BF, TileRayBf, TileRay>;
+  constexpr int NA = BF ? 8 : 3; // sphere registers per tile
+  __shared__ QRay q_ray[T];
   __shared__ unsigned long long q_key[T];
   __shared__ int q_cnt[W], q_live[W]; // per wave: rays queued this iteration, pool not yet dry
   // The pool of rt_path.h, one per WAVE, run as the small-world kernel runs it (rt_wavepath.h: no barriers, prefix sums in
@@ -112,7 +195,7 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
     if (L.active) {
       my_q = 64 * wave + __popcll(live & ((1ull << lane) - 1ull));
       const int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
-      q_ray[my_q] = TileRay::make(L.ray, self);
+      q_ray[my_q] = QRay::make(L.ray, self);
       q_key[my_q] = ~0ull;
     }
     __syncthreads();
@@ -132,12 +215,18 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
       const int first = pass * S * W;
       const int first_w = first + __builtin_amdgcn_readfirstlane(wave);
       const int n_s = min(S, max(0, (n_tiles - first_w + W - 1) / W));
-      float a1[S], a2[S], a3[S];
+      float a[S][NA];
 #pragma unroll
       for (int s_ = 0; s_ < S; ++s_) {
         const int tile = min(first + s_ * W + wave, n_tiles - 1); // tiles past n_s are not multiplied
-        const float *rec = s.wide_tiles + (size_t)tile * 192 + lane;
-        a1[s_] = rec[0], a2[s_] = rec[64], a3[s_] = rec[128];
+        const float *rec = s.wide_tiles + (size_t)tile * RT_TILE_WORDS;
+        if constexpr (BF) {
+          const float4 lo = reinterpret_cast<const float4 *>(rec)[lane], hi = reinterpret_cast<const float4 *>(rec)[64 + lane];
+          a[s_][0] = lo.x, a[s_][1] = lo.y, a[s_][2] = lo.z, a[s_][3] = lo.w;
+          a[s_][4] = hi.x, a[s_][5] = hi.y, a[s_][6] = hi.z, a[s_][7] = hi.w;
+        } else {
+          a[s_][0] = rec[lane], a[s_][1] = rec[64 + lane], a[s_][2] = rec[128 + lane];
+        }
       }
       for (int rt = 0; rt < 2 * W; ++rt) { // the two 32-ray blocks of every wave's slots
         const int n_w = __builtin_amdgcn_readfirstlane(q_cnt[rt >> 1]), r0 = (rt & 1) * 32;
@@ -146,8 +235,12 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
         const int n = 64 * (rt >> 1) + r0 + col;
         const bool valid = r0 + col < n_w;
         const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[valid ? n : 64 * (rt >> 1)]);
-        const float4 qa = rec[half], qc = rec[2];
-        const float bq1 = qa.x, bq2 = qa.y, cq1 = qa.z, cq2 = half ? 1.f : qa.w;
+        float4 qb0, qb1, qc0, qc1, qc; // B_b and B_c (binary32 build: qb0 alone carries both), and the lane's own quad
+        if constexpr (BF) {
+          qb0 = rec[half], qb1 = rec[2], qc0 = rec[3 + half], qc1 = rec[5], qc = rec[6];
+        } else {
+          qb0 = rec[half], qc = rec[2];
+        }
         const float oo = valid ? qc.x : INF_F; // a lane past the queue's end asks d > +inf
         const float tmin_u = qc.y, inv_len = qc.z;
         const int self = __float_as_int(qc.w);
@@ -157,10 +250,29 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
           __builtin_amdgcn_sched_barrier(0); // one tile at a time: interleaving the tiles' accumulators spills them
           if (s_ < n_s) { // uniform over the wave
             f32x16 b = {0}, c = {0};
-            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], bq1, b, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], cq1, c, 0, 0, 0);
-            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s_], bq2, b, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s_], cq2, c, 0, 0, 0);
+            if constexpr (BF) {
+              union Op {
+                bf16x8 v;
+                float f[4];
+              };
+              Op a0, a1, b0, b1, c0, c1;
+              a0.f[0] = a[s_][0], a0.f[1] = a[s_][1], a0.f[2] = a[s_][2], a0.f[3] = a[s_][3];
+              a1.f[0] = a[s_][4], a1.f[1] = a[s_][5], a1.f[2] = a[s_][6], a1.f[3] = a[s_][7];
+              b0.f[0] = qb0.x, b0.f[1] = qb0.y, b0.f[2] = qb0.z, b0.f[3] = qb0.w;
+              b1.f[0] = qb1.x, b1.f[1] = qb1.y, b1.f[2] = qb1.z, b1.f[3] = qb1.w;
+              c0.f[0] = qc0.x, c0.f[1] = qc0.y, c0.f[2] = qc0.z, c0.f[3] = qc0.w;
+              c1.f[0] = qc1.x, c1.f[1] = qc1.y, c1.f[2] = qc1.z, c1.f[3] = qc1.w;
+              b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b0.v, b, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, c0.v, c, 0, 0, 0);
+              b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, b, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, c1.v, c, 0, 0, 0);
+            } else {
+              const float bq1 = qb0.x, bq2 = qb0.y, cq1 = qb0.z, cq2 = half ? 1.f : qb0.w;
+              b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], bq1, b, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], cq1, c, 0, 0, 0);
+              b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][1], bq2, b, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][2], cq2, c, 0, 0, 0);
+            }
             // (8 v_pk_fma_f32 on a negated c product instead of these 16 v_fma: measured, no gain — 9929 -> 9949 and 1423 -> 1388
             // Mrays/s: the fp32 lanes, not the issue slots, are what a tile waits for)
             float d[16];

@@ -71,6 +71,11 @@ struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit sha
   uint32_t material;
 };
 
+#ifndef RT_TILE_BF16
+#define RT_TILE_BF16 1 // the tile kernel's sphere filter on bf16 MFMAs (operands split 3-way); 0: on binary32 MFMAs (rounds 2-3a)
+#endif
+constexpr int RT_TILE_WORDS = RT_TILE_BF16 ? 512 : 192;
+
 struct Scene {
   // scan lists
   const ScanRec *spheres; int32_t n_spheres;
@@ -79,8 +84,11 @@ struct Scene {
   // ones scanned per lane instead (big spheres, a short leftover), ascending too
   const ScanRec *wide_recs; const float *wide_iso; int32_t n_wide, wide_rows;
   const ScanRec *wide_lane; int32_t n_wide_lane;
-  // the same register spheres as MFMA operands (rt_tile.h): per tile of 32, three rows of 64 floats — lane l of a wave takes
-  // cx | cy, cz | 1, cz | k of sphere l % 32 for l < 32 | l >= 32; a place past n_wide holds 0 0 0 and k = +inf (never hit)
+  // the same register spheres as MFMA operands (rt_tile.h), RT_TILE_WORDS 32-bit words per tile of 32:
+  //  RT_TILE_BF16 (default): 2 K-chunks x 64 lanes x 4 words of bf16 pairs — the 3-way bf16 splits of cx cy cz k laid out in the
+  //    32 K slots of two v_mfma_f32_32x32x16_bf16 (rt_tile.h says which slot holds what); a place past n_wide: centre 0, k = 1e30
+  //  binary32 build: three rows of 64 floats — lane l takes cx | cy, cz | 1, cz | k of sphere l % 32 for l < 32 | l >= 32;
+  //    a place past n_wide holds 0 0 0 and k = +inf (never hit)
   const float *wide_tiles; int32_t n_wide_tiles;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   // RT_FLAG_ACCEL_BVH (rt_bvh.h): heap of n_bvh_nodes slots (0: no hierarchy); the spheres inside it regrouped by

@@ -8,7 +8,7 @@
 #endif
 #define RT_T(WW, CSG) reinterpret_cast<const void *>(rtd::k_render_path_tile<RT_TILE_S, WW, CSG>)
 
-// 8 sphere tiles per wave and pass (measured against 4 and 16, see rt_tile.h), `waves` waves per workgroup; worlds without
+// S = 8 sphere tiles per wave and pass (measured against 4 and 16 in both builds, see rt_tile.h), `waves` waves per workgroup; worlds without
 // CSG objects run the variants compiled without the evaluators (fewer registers spilled)
 const void *rt_tile_kernel(int waves, bool csg) {
   switch (waves) {
@@ -18,3 +18,5 @@ const void *rt_tile_kernel(int waves, bool csg) {
   default: return csg ? RT_T(8, true) : RT_T(8, false);
   }
 }
+
+int rt_tile_s() { return RT_TILE_S; }

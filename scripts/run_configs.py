@@ -37,7 +37,7 @@ def run(label, scene, mode, w, h, aa, reps=3):
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     world.close()
-    print(json.dumps({"config": label, "mode": mode.mode, "size": f"{w}x{h} AA={aa}", "objects": scene.count("n_objects"),
+    print(json.dumps({"config": label, "mode": mode.mode, "size": f"{w}x{h} AA={aa}", "objects": scene.count("n_objects"), "kernel": st.kernel.decode(),
                       "rays": int(st.rays), "samples": int(st.samples), "capped_samples": int(st.capped_samples),
                       "frame_ms": best * 1e3, "Mrays_per_s": st.rays / best / 1e6,
                       "mean_radiance": float(out.mean()),
