@@ -7,11 +7,12 @@
 
 Workload (the headline): the synthetic 4096-random-sphere + floor + sky scene (raytracer_amd/synth.py), --mode path,
 1920x1080, AA=4 (16 spp), n_rays=10, roulette=3, max-depth=5.  Every object is tested for every ray (World::ray_intersection is a
-linear scan, reference include/shapes.hpp:547-561); a ray = one such closest-hit query.  A whole frame is 4.04e11 rays, ~270 s
-on one MI355X, so a STEP is one row-cyclic SHARE of it: 1/32 of the rows (rows k, k + 32, k + 64, ...: every share is the same
-mix of sky, floor and sphere rows; shares differ by < 2 % in cost), 1.26e10 rays, ~8.5 s.  Step j renders share
-(j * n_gpus + rank) mod 32: consecutive steps walk through the frame, a run of 32 / n_gpus steps renders all of it, and
-`value` (rays / time) IS the whole-frame rate; `frame_ms_estimate` = 32 x ms_per_step / n_gpus.
+linear scan, reference include/shapes.hpp:547-561); a ray = one such closest-hit query.  A whole frame is 4.04e11 rays, ~180 s
+on one MI355X, so a STEP is one row-cyclic SHARE of it: 1/16 of the rows (rows k, k + 16, k + 32, ...: every share is the same
+mix of sky, floor and sphere rows; shares differ by < 2 % in cost), 2.5e10 rays, ~11 s.  Step j renders share
+(j * n_gpus + rank) mod 16: consecutive steps walk through the frame, a run of 16 / n_gpus steps renders all of it, and
+`value` (rays / time) is the whole-frame rate up to the end of a launch, where the pools drain at low occupancy (~0.3 s per
+launch: 1/32 shares measure 5 % less); `frame_ms_estimate` = 16 x ms_per_step / n_gpus.
 
 With --gpus N every rank renders its own share of the step (per-GPU work is fixed as N grows: "scaling": "weak"; the job is
 still one frame, N shares of it at a time) into HBM and rank 0 gathers the N shares over RCCL into the frame buffer.  With no
@@ -21,7 +22,7 @@ before anything touches the GPU) and relays rank 0's line.  Scene and buffers ar
 At N = 1 the line also carries `configs`: BASELINE.json's configs measured in the same run — C1 (onoff), C2 (flat and
 pointlight), C3, C4 (path on the reference's sample scenes, full size), the full N=512 frame (round 2's default) with and
 without the matrix-core filter — each with its kernel, ray count, kernel ms (HIP events of the same launch) and roofline block.
-configs[4] (3840x2160) is four times the headline frame: 128 shares of this cost.
+configs[4] (3840x2160) is four times the headline frame: 64 shares of this cost.
 
 Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
@@ -292,7 +293,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=4)
     ap.add_argument("--spheres", type=int, default=4096)
-    ap.add_argument("--shares", type=int, default=32, help="a step renders 1 / SHARES of the frame's rows per rank (row-cyclic); 1 = the whole frame per step")
+    ap.add_argument("--shares", type=int, default=16, help="a step renders 1 / SHARES of the frame's rows per rank (row-cyclic); 1 = the whole frame per step")
     ap.add_argument("--scene", default=None, choices=["demo_onoff", "demo_path", "csg_example"],
                     help="one of the reference's sample scenes (flattened fixture in tests/golden/) instead of the synthetic one")
     ap.add_argument("--n_rays", type=int, default=10)
@@ -422,7 +423,7 @@ def main():
 
     if rank == 0:
         census = scene_census(scene)
-        default_workload = (not args.scene and args.spheres == 4096 and args.width == 1920 and args.height == 1080 and args.aa == 4 and args.shares == 32
+        default_workload = (not args.scene and args.spheres == 4096 and args.width == 1920 and args.height == 1080 and args.aa == 4 and args.shares == 16
                             and (args.n_rays, args.roulette, args.max_depth) == (10, 3, 5) and not args.bvh and not args.valu_only)
         rays_per_step_rank0 = rays_local / args.steps
         out = {

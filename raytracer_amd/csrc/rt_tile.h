@@ -143,9 +143,20 @@ struct alignas(16) TileRayBf {
     r.ox = ray.o.x, r.oy = ray.o.y, r.oz = ray.o.z, r.tmin = ray.tmin;
     return r;
   }
-  RT_DEV void restore(Ray &ray) const {
-    ray.o = mk3(ox, oy, oz);
-    ray.tmin = tmin;
+  // In LDS the eight quads of record n are stored swizzled: logical quad q sits at physical quad q ^ ((n >> 1) & 7).  With plain
+  // 128-byte records the 16 lanes one ds_read_b128 cycle serves would find the same quad of consecutive records in only two bank
+  // groups (record stride = half the 64 banks): measured 0.85 conflict cycles per LDS cycle; swizzled they cover all 64 banks.
+  RT_DEV static int quad_index(int n, int q) { return 8 * n + (q ^ ((n >> 1) & 7)); }
+  RT_DEV void store(float4 *quads, int n) const {
+    const float4 *src = reinterpret_cast<const float4 *>(this);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      quads[quad_index(n, q)] = src[q];
+  }
+  RT_DEV static void restore(const float4 *quads, int n, Ray &ray) {
+    const float4 v = quads[quad_index(n, 7)];
+    ray.o = mk3(v.x, v.y, v.z);
+    ray.tmin = v.w;
   }
 };
 static_assert(sizeof(TileRayBf) == 128, "eight quads");
@@ -195,7 +206,10 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
     if (L.active) {
       my_q = 64 * wave + __popcll(live & ((1ull << lane) - 1ull));
       const int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
-      q_ray[my_q] = QRay::make(L.ray, self);
+      if constexpr (BF)
+        QRay::make(L.ray, self).store(reinterpret_cast<float4 *>(q_ray), my_q);
+      else
+        q_ray[my_q] = QRay::make(L.ray, self);
       q_key[my_q] = ~0ull;
     }
     __syncthreads();
@@ -234,87 +248,102 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
           continue;
         const int n = 64 * (rt >> 1) + r0 + col;
         const bool valid = r0 + col < n_w;
-        const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[valid ? n : 64 * (rt >> 1)]);
+        const int slot = valid ? n : 64 * (rt >> 1);
         float4 qb0, qb1, qc0, qc1, qc; // B_b and B_c (binary32 build: qb0 alone carries both), and the lane's own quad
         if constexpr (BF) {
-          qb0 = rec[half], qb1 = rec[2], qc0 = rec[3 + half], qc1 = rec[5], qc = rec[6];
+          const float4 *quads = reinterpret_cast<const float4 *>(q_ray) + 8 * slot;
+          const int sw = (slot >> 1) & 7;
+          qb0 = quads[half ^ sw], qb1 = quads[2 ^ sw], qc0 = quads[(3 + half) ^ sw], qc1 = quads[5 ^ sw], qc = quads[6 ^ sw];
         } else {
+          const float4 *rec = reinterpret_cast<const float4 *>(&q_ray[slot]);
           qb0 = rec[half], qc = rec[2];
         }
         const float oo = valid ? qc.x : INF_F; // a lane past the queue's end asks d > +inf
         const float tmin_u = qc.y, inv_len = qc.z;
         const int self = __float_as_int(qc.w);
         unsigned long long best = ~0ull;
+        // the four (bf16: 4 x K = 16; binary32: 4 x K = 2) MFMAs of tile s_ of this pass against the ray block in qb0 .. qc1
+        auto products = [&](int s_, f32x16 &b, f32x16 &c) {
+          b = f32x16{0}, c = f32x16{0};
+          if constexpr (BF) {
+            union Op {
+              bf16x8 v;
+              float f[4];
+            };
+            Op a0, a1, b0, b1, c0, c1;
+            a0.f[0] = a[s_][0], a0.f[1] = a[s_][1], a0.f[2] = a[s_][2], a0.f[3] = a[s_][3];
+            a1.f[0] = a[s_][4], a1.f[1] = a[s_][5], a1.f[2] = a[s_][6], a1.f[3] = a[s_][7];
+            b0.f[0] = qb0.x, b0.f[1] = qb0.y, b0.f[2] = qb0.z, b0.f[3] = qb0.w;
+            b1.f[0] = qb1.x, b1.f[1] = qb1.y, b1.f[2] = qb1.z, b1.f[3] = qb1.w;
+            c0.f[0] = qc0.x, c0.f[1] = qc0.y, c0.f[2] = qc0.z, c0.f[3] = qc0.w;
+            c1.f[0] = qc1.x, c1.f[1] = qc1.y, c1.f[2] = qc1.z, c1.f[3] = qc1.w;
+            b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b0.v, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, c0.v, c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, c1.v, c, 0, 0, 0);
+          } else {
+            const float bq1 = qb0.x, bq2 = qb0.y, cq1 = qb0.z, cq2 = half ? 1.f : qb0.w;
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], bq1, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], cq1, c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][1], bq2, b, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][2], cq2, c, 0, 0, 0);
+          }
+        };
+        // what the vector ALU does with a tile's products: d = b^2 - c, its maximum, and — where some d beats O.O — the candidates
+        auto consume = [&](int s_, const f32x16 &b, const f32x16 &c) {
+          // (8 v_pk_fma_f32 on a negated c product instead of these 16 v_fma: measured, no gain — 9929 -> 9949 and 1423 -> 1388
+          // Mrays/s with the binary32 MFMAs)
+          float d[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            d[r] = fmaf(b[r], b[r], -c[r]);
+          // maxima of five blocks of 3 registers (v_max3_f32 each) and the tile maximum: 8 instructions for the 16 values
+          float g[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            g[k] = fmaxf(fmaxf(d[3 * k], d[3 * k + 1]), d[3 * k + 2]);
+          const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(fmaxf(g[3], g[4]), d[15]));
+          if (m > oo) { // this ray's line meets one of the tile's spheres
+            // the tile's first position is wave-uniform; the lane's own part (the lower or upper 4 of each 8 rows) is made
+            // opaque here so that the 256 positions of a pass are not all computed ahead of the loops and kept in registers
+            int h4 = 4 * half;
+            asm volatile("" : "+v"(h4));
+            const int base = (first_w + s_ * W) * 32 + h4; // position of this lane's row 0
+            const int self_rel = self - base;
+            auto candidate = [&](int r) {
+              if (d[r] > oo) {
+                const int row = 8 * (r >> 2) + (r & 3); // a literal
+                // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+                const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
+                const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                const float u = u1 < tmin_u ? u2 : u1;
+                if (u > tmin_u && self_rel != row) {
+                  const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(base + row);
+                  best = min(best, key); // equal t: the lowest position = the lowest object index, the reference's strict `<`
+                }
+              }
+            };
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              if (g[k] > oo) {
+                candidate(3 * k);
+                candidate(3 * k + 1);
+                candidate(3 * k + 2);
+              }
+            }
+            candidate(15);
+          }
+        };
+        // (Issuing the MFMAs of tile s_ + 1 ahead of the vector work on tile s_, into a second pair of accumulators, was built and
+        // measured: the compiler interleaves them as hoped, but N=4096 gains 2 % and N=512 loses 10 % to the spills — with three
+        // waves per SIMD the two pipes already overlap across waves, and counters show the SIMDs 92 % busy, vector ALU 64 %.)
 #pragma unroll
         for (int s_ = 0; s_ < S; ++s_) {
           __builtin_amdgcn_sched_barrier(0); // one tile at a time: interleaving the tiles' accumulators spills them
           if (s_ < n_s) { // uniform over the wave
-            f32x16 b = {0}, c = {0};
-            if constexpr (BF) {
-              union Op {
-                bf16x8 v;
-                float f[4];
-              };
-              Op a0, a1, b0, b1, c0, c1;
-              a0.f[0] = a[s_][0], a0.f[1] = a[s_][1], a0.f[2] = a[s_][2], a0.f[3] = a[s_][3];
-              a1.f[0] = a[s_][4], a1.f[1] = a[s_][5], a1.f[2] = a[s_][6], a1.f[3] = a[s_][7];
-              b0.f[0] = qb0.x, b0.f[1] = qb0.y, b0.f[2] = qb0.z, b0.f[3] = qb0.w;
-              b1.f[0] = qb1.x, b1.f[1] = qb1.y, b1.f[2] = qb1.z, b1.f[3] = qb1.w;
-              c0.f[0] = qc0.x, c0.f[1] = qc0.y, c0.f[2] = qc0.z, c0.f[3] = qc0.w;
-              c1.f[0] = qc1.x, c1.f[1] = qc1.y, c1.f[2] = qc1.z, c1.f[3] = qc1.w;
-              b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b0.v, b, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, c0.v, c, 0, 0, 0);
-              b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, b, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, c1.v, c, 0, 0, 0);
-            } else {
-              const float bq1 = qb0.x, bq2 = qb0.y, cq1 = qb0.z, cq2 = half ? 1.f : qb0.w;
-              b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], bq1, b, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][0], cq1, c, 0, 0, 0);
-              b = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][1], bq2, b, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][2], cq2, c, 0, 0, 0);
-            }
-            // (8 v_pk_fma_f32 on a negated c product instead of these 16 v_fma: measured, no gain — 9929 -> 9949 and 1423 -> 1388
-            // Mrays/s: the fp32 lanes, not the issue slots, are what a tile waits for)
-            float d[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              d[r] = fmaf(b[r], b[r], -c[r]);
-            // maxima of five blocks of 3 registers (v_max3_f32 each) and the tile maximum: 8 instructions for the 16 values
-            float g[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-              g[k] = fmaxf(fmaxf(d[3 * k], d[3 * k + 1]), d[3 * k + 2]);
-            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(fmaxf(g[3], g[4]), d[15]));
-            if (m > oo) { // this ray's line meets one of the tile's spheres
-              // the tile's first position is wave-uniform; the lane's own part (the lower or upper 4 of each 8 rows) is made
-              // opaque here so that the 256 positions of a pass are not all computed ahead of the loops and kept in registers
-              int h4 = 4 * half;
-              asm volatile("" : "+v"(h4));
-              const int base = (first_w + s_ * W) * 32 + h4; // position of this lane's row 0
-              const int self_rel = self - base;
-              auto candidate = [&](int r) {
-                if (d[r] > oo) {
-                  const int row = 8 * (r >> 2) + (r & 3); // a literal
-                  // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
-                  const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
-                  const float u1 = -b[r] - sq, u2 = -b[r] + sq;
-                  const float u = u1 < tmin_u ? u2 : u1;
-                  if (u > tmin_u && self_rel != row) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(base + row);
-                    best = min(best, key); // equal t: the lowest position = the lowest object index, the reference's strict `<`
-                  }
-                }
-              };
-#pragma unroll
-              for (int k = 0; k < 5; ++k) {
-                if (g[k] > oo) {
-                  candidate(3 * k);
-                  candidate(3 * k + 1);
-                  candidate(3 * k + 2);
-                }
-              }
-              candidate(15);
-            }
+            f32x16 b, c;
+            products(s_, b, c);
+            consume(s_, b, c);
           }
         }
         if (best != ~0ull)
@@ -334,7 +363,10 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile(Scene 
     h.object = h.shape = -1;
     h.t = 0.f;
     h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
-    q_ray[max(my_q, 0)].restore(L.ray); // every lane, so that no lane's old values stay live across the scan
+    if constexpr (BF) // every lane, so that no lane's old values stay live across the scan
+      QRay::restore(reinterpret_cast<const float4 *>(q_ray), max(my_q, 0), L.ray);
+    else
+      q_ray[max(my_q, 0)].restore(L.ray);
     if (L.active) {
       const unsigned long long key = q_key[my_q];
       Best best;

@@ -10,7 +10,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "r3prof"), os.path.join(ROOT, "profiles", "r3")
 COMMON = ("; one rocprofv3 --pmc run per counter block (SQ x8 | GRBM + SQ x7 | FETCH_SIZE | WRITE_SIZE | VALU instruction classes | activity and "
-          "LDS atomics); counters are sums over all launches of a pass; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them")
+          "LDS atomics | matrix pipe); counters are sums over all launches of a pass; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them")
 
 
 def rays_of(log):
@@ -44,6 +44,12 @@ def summarise(name, command):
          "active_lanes_per_valu_instr": c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_INSTS_VALU"], 1.0),
          "hbm_bytes_per_launch": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / launches,
          "hbm_write_bytes_per_launch": c["WRITE_SIZE"] * 1024 / launches}
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_bf16), summed over the SIMDs
+        secs7 = list(e["kernel_seconds_per_pass"].values())[-1]
+        d["mfma_busy_share_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (secs7 * clock * 1024)
+        d["mfma_instr_per_ray"] = (c.get("SQ_INSTS_VALU_MFMA_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_F32", 0.0)) / total_rays
+        d["mfma_busy_cycles_per_mfma"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("SQ_INSTS_VALU_MFMA_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_F32", 0.0), 1.0)
     out = {"command": command + COMMON, "kernel": kernel, "launches": launches, "rays_per_launch": total_rays / launches, "counters": c,
            "kernel_seconds_per_pass": e["kernel_seconds_per_pass"], "lds_bytes": e["lds_bytes"], "scratch_bytes": e["scratch_bytes"],
            "vgprs": e["vgprs"], "workgroup": e["workgroup"], "derived": d}
@@ -56,7 +62,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, "a_bench_line.json"))
     shutil.copy(os.path.join(SRC, "kernel_stats.csv"), os.path.join(DST, "a_bench_kernel_stats.csv"))
-    summarise("n4096_share", "scripts/pmc_run.sh r3_n4096_share -- --steps 1 --warmup 1 --no-cpu-baseline --no-configs   (bench.py defaults: 4096 spheres, 1920x1080 AA=4, shares 0 and 1 of 32)")
+    summarise("n4096_share", "scripts/pmc_run.sh r3_n4096_share -- --steps 1 --warmup 1 --no-cpu-baseline --no-configs   (bench.py defaults: 4096 spheres, 1920x1080 AA=4, shares 0 and 1 of 16)")
     summarise("c3", "scripts/pmc_run.sh r3_c3 -- --steps 2 --warmup 1 ... --scene demo_path --width 1280 --height 960 --aa 2 --shares 1   (C3, path 10/3/5)")
     summarise("c4", "scripts/pmc_run.sh r3_c4 -- --steps 2 --warmup 1 ... --scene csg_example --shares 1   (C4: 1920x1080 AA=4, path 10/3/5)")
     summarise("n512", "scripts/pmc_run.sh r3_n512 -- --steps 1 --warmup 1 ... --spheres 512 --shares 1   (the whole N=512 1920x1080 AA=4 frame per launch)")
