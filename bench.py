@@ -128,9 +128,11 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
        frac_algorithmic = rays x algorithmic_flops_per_ray (the reference's arithmetic as written) / kernel_ms / peak
                           — exceeds 1 where the kernel does the same job with fewer flops (18 instead of 52 per sphere test)
        achieved / frac  = the executed figures (the contract's field names)
-       traffic          = HBM-side bytes per launch from the PMC counters of `traffic_source` (FETCH_SIZE + WRITE_SIZE, each in its own
-                          rocprofv3 --pmc pass of the same configuration), null when no such profile is committed — never measured in the
-                          timed run itself
+       traffic          = HBM-side bytes per launch from the PMC counters of `traffic_source`: 2 x FETCH_SIZE + WRITE_SIZE, each counter in
+                          its own rocprofv3 --pmc pass of the same configuration, in KB as rocprofv3 reports them, FETCH_SIZE doubled as
+                          MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64); the counters sit on the L2's fabric
+                          side, so Infinity-Cache hits are included: an upper bound on HBM bytes.  null when no such profile is committed —
+                          never measured in the timed run itself
        valu_issue       = for the kernels that are NOT flop-bound (a handful of objects per ray): the bound that applies — the
                           vector ALU's issue slots.  VALU wave-instructions per ray by class from the profile's SQ_INSTS_VALU* counters x
                           the measured issue cost of each class, against the SIMD-cycles per ray of this very launch."""
@@ -160,7 +162,7 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
                "traffic": None, "traffic_source": None, "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms}
         if profile is not None and "FETCH_SIZE" in profile["counters"] and "WRITE_SIZE" in profile["counters"]:
             c, launches = profile["counters"], float(profile.get("launches", 1))
-            out["traffic"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
+            out["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
             out["traffic_source"] = profile["_source"]
         return out
     out = {"bound": "mfma" if "path_tile<" in kernel else "valu", "peak_kind": "fp32, vector = matrix: v_mfma_f32_32x32x2_f32 runs on the VALU's fp32 lanes (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)",
@@ -173,7 +175,7 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
     if profile is not None:
         c, launches = profile["counters"], float(profile.get("launches", 1))
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            out["traffic"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
+            out["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
             out["traffic_source"] = profile["_source"]
         if "SQ_INSTS_VALU_FMA_F32" in c:
             n = float(profile["rays_per_launch"]) * launches
@@ -186,7 +188,10 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
             out["valu_issue"] = {"valu_wave_instr_per_ray": total, "fp32_add_mul_fma_per_ray": fast, "transcendental_per_ray": trans,
                                  "modelled_valu_cycles_per_ray": model, "simd_cycles_per_ray_this_launch": measured, "clock_ghz": clk,
                                  "frac": model / measured, "source": profile["_source"],
-                                 "note": "frac near 1 = the vector ALU issues all the time; 'other' is priced at 4.2 cycles although its plain moves and logic ops issue at 2.3: an upper estimate"}
+                                 "saturated": model / measured >= 0.9,
+                                 "note": "modelled / measured issue cycles: near 1 = the vector ALU issues all the time.  'other' is priced at 4.2 cycles although the "
+                                         "plain moves, integer adds and logic ops in it issue at 2.3, so the model is an upper estimate and can exceed 1 by that "
+                                         "margin (C3 / C4: 1.07-1.08)"}
     return out
 
 
