@@ -204,7 +204,7 @@ def cpu_baseline(scene, text, args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from raytracer_amd import abi
-    w, h, aa = args.cpu_width, args.cpu_height, 1  # defaults: 12x7 on the 4096-sphere world: ~15 s of the reference + ~20 s of the port on one core of the GPU box's host
+    w, h, aa = args.cpu_width, args.cpu_height, 1  # defaults: 8x5 on the 4096-sphere world: ~5 s of the reference + ~7 s of the port on one core of the GPU box's host
     cfg = O.make_cfg(w, h, "path", spp_edge=aa, n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth,
                      seq_number=54, rng_mode=abi.RT_RNG_SERIAL_REFERENCE)
     t0 = time.perf_counter()
@@ -304,8 +304,8 @@ def main():
     ap.add_argument("--n_rays", type=int, default=10)
     ap.add_argument("--roulette", type=int, default=3)
     ap.add_argument("--max-depth", dest="max_depth", type=int, default=5)
-    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=12)
-    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=7)
+    ap.add_argument("--cpu-width", dest="cpu_width", type=int, default=8)
+    ap.add_argument("--cpu-height", dest="cpu_height", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records of the N=1 line")
     ap.add_argument("--bvh", action="store_true",

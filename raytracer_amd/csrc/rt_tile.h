@@ -99,7 +99,7 @@ struct alignas(16) TileRay {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // x = p[0] + p[1] + p[2] exactly; parts as bf16 bit patterns
-RT_DEV inline void bf16_split3(float x, uint32_t p[3]) {
+RT_DEV void bf16_split3(float x, uint32_t p[3]) {
   const auto rn = [](float v) { // round to nearest even; finite values
     const uint32_t u = __float_as_uint(v);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;

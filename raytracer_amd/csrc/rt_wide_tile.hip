@@ -14,8 +14,10 @@ const void *rt_tile_kernel(int waves, bool csg) {
   switch (waves) {
   case 1: return csg ? RT_T(1, true) : RT_T(1, false);
   case 2: return csg ? RT_T(2, true) : RT_T(2, false);
-  case 4: return csg ? RT_T(4, true) : RT_T(4, false);
-  default: return csg ? RT_T(8, true) : RT_T(8, false);
+#ifdef RT_TUNING // W = 8 is dominated at every measured size (rt_tile.h) and its 100 KB of LDS leave one workgroup per CU: A/B builds only
+  case 8: return csg ? RT_T(8, true) : RT_T(8, false);
+#endif
+  default: return csg ? RT_T(4, true) : RT_T(4, false);
   }
 }
 
