@@ -59,18 +59,24 @@ def summarise(name, command):
 
 
 def main():
+    import sys
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, "a_bench_line.json"))
-    shutil.copy(os.path.join(SRC, "kernel_stats.csv"), os.path.join(DST, "a_bench_kernel_stats.csv"))
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":
+        shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, "a_bench_line.json"))
+        shutil.copy(os.path.join(SRC, "stats_bench.json"), os.path.join(DST, "a_bench_line_profiled_run.json"))
+        shutil.copy(os.path.join(SRC, "kernel_stats.csv"), os.path.join(DST, "a_bench_kernel_stats.csv"))
+        b = json.load(open(os.path.join(DST, "a_bench_line.json")))
+        print("bench:", round(b["value"], 1), "Mrays/s,", round(b["ms_per_step"], 1), "ms, frac", round(b["roofline"]["frac"], 4), b["roofline"]["kernel"],
+              "traffic", b["roofline"]["traffic"])
+        for c in b["configs"]:
+            print("  ", c["id"], round(c["kernel_ms"], 3), "ms", round(c["Mrays_per_s"]), "Mrays/s frac", round(c["roofline"]["frac"], 3), c["kernel"],
+                  (c["roofline"].get("valu_issue") or {}).get("frac"))
+        print(open(os.path.join(DST, "a_bench_kernel_stats.csv")).read()[:1500])
+        return
     summarise("n4096_share", "scripts/pmc_run.sh r3_n4096_share -- --steps 1 --warmup 1 --no-cpu-baseline --no-configs   (bench.py defaults: 4096 spheres, 1920x1080 AA=4, shares 0 and 1 of 16)")
     summarise("c3", "scripts/pmc_run.sh r3_c3 -- --steps 2 --warmup 1 ... --scene demo_path --width 1280 --height 960 --aa 2 --shares 1   (C3, path 10/3/5)")
     summarise("c4", "scripts/pmc_run.sh r3_c4 -- --steps 2 --warmup 1 ... --scene csg_example --shares 1   (C4: 1920x1080 AA=4, path 10/3/5)")
     summarise("n512", "scripts/pmc_run.sh r3_n512 -- --steps 1 --warmup 1 ... --spheres 512 --shares 1   (the whole N=512 1920x1080 AA=4 frame per launch)")
-    b = json.load(open(os.path.join(DST, "a_bench_line.json")))
-    print("bench:", round(b["value"], 1), "Mrays/s,", round(b["ms_per_step"], 1), "ms, frac", round(b["roofline"]["frac"], 4), b["roofline"]["kernel"])
-    for c in b["configs"]:
-        print("  ", c["id"], round(c["kernel_ms"], 3), "ms", round(c["Mrays_per_s"]), "Mrays/s frac", round(c["roofline"]["frac"], 3), c["kernel"])
-    print(open(os.path.join(DST, "a_bench_kernel_stats.csv")).read()[:1500])
 
 
 if __name__ == "__main__":
