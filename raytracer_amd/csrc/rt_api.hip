@@ -351,6 +351,38 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     grid = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(sc->n_cus) * per_cu));
     // one node stack per wave: at most 64 nodes per depth level (rt_path.h: the stack discipline)
     stacks_per_block = static_cast<int>(block / 64);
+    // Samples a wave reserves from the call's queue per atomic (RenderParams::sample_chunk).  A wave finishes alone what it has
+    // reserved.  Until round 3 a reservation was 128 samples whatever the launch; now large worlds reserve exactly what the idle
+    // lanes ask for and small worlds 1/32 of a wave's share of the launch, at most 128 (one address takes about 75 M atomics a
+    // second: C3 makes 28 M).  Measured (scripts/ab_chunk.sh): little — N=4096 480x136 3606 -> 3553 ms, C3 11.9 -> 11.8 ms — the
+    // tail of a launch is set by fresh_max below.
+    {
+      const uint64_t n_waves = static_cast<uint64_t>(grid) * (block / 64);
+#ifdef RT_TUNING
+      static const int div_env = [] { const char *e = std::getenv("RT_CHUNK_DIV"); return e && *e ? std::atoi(e) : 32; }();
+      static const int large_env = [] { const char *e = std::getenv("RT_CHUNK_LARGE"); return e && *e ? std::atoi(e) : 1; }();
+#else
+      constexpr int div_env = 32, large_env = 1;
+#endif
+      const uint64_t share = p.n_samples / std::max<uint64_t>(n_waves * static_cast<uint64_t>(div_env), 1);
+      p.sample_chunk = static_cast<int32_t>(std::clamp<uint64_t>(share, 1, 128));
+      if (use_wide || use_bvh)
+        p.sample_chunk = std::min(p.sample_chunk, large_env);
+      // Fresh samples per iteration (RenderParams::fresh_max).  A wave tops up only when its whole stack holds fewer children than
+      // it has lanes; what it takes then it finishes as one batch.  With 64 at a time a batch of the N=4096 scene is 770 000 rays
+      // (0.9 s), and the batch a wave is in when the queue runs dry is the launch's tail: 0.25 s per launch measured
+      // (scripts/ab_slices.sh).  Large worlds take 4 at a time (N=4096 480x136: 3497 -> 3355 ms, N=512 unchanged; the few
+      // under-filled iterations after a top-up vanish against 190 iterations per sample); small worlds, whose samples are a
+      // dozen iterations long, lose with any cap (C4: 36.9 ms at 64, 38.5 at 16, 47 at 4) and keep 64.  Shrinking the cap only as the
+      // queue runs dry (guided self-scheduling: remaining samples / (waves x 1 ... 8)) was built and measured too: C3 / C4 12.0 /
+      // 37.4 ms against 11.8 / 36.9 — not kept.
+      p.fresh_max = use_wide ? 4 : 64;
+#ifdef RT_TUNING
+      static const int fresh_env = [] { const char *e = std::getenv("RT_FRESH_MAX"); return e && *e ? std::atoi(e) : 0; }();
+      if (fresh_env > 0)
+        p.fresh_max = std::min(fresh_env, 64);
+#endif
+    }
     p.pool_cap = nodes_per_level * (cfg->n_rays == 1 ? 1 : std::max(cfg->max_depth, 1));
     const size_t stack_bytes = static_cast<size_t>(stacks_per_block) * node_words * static_cast<size_t>(p.pool_cap) * sizeof(float); // per workgroup
     if (ws.fixed) {

@@ -88,7 +88,6 @@ RT_DEV void wave_add_tally(unsigned long long *counters, int which, unsigned lon
 struct PathLdsLimits {
   static constexpr int SHAPES = 64, MATERIALS = 32, PIGMENTS = 64, CSG_LEAVES = 32, CSG_PATH = 128, CSG_NODES = 32, CSG_PROG = 128, CSG_TOPS = 8;
 };
-constexpr int SAMPLE_CHUNK = 2; // pixel samples fetched from the call's queue per top-up, in units of T
 
 RT_DEV uint64_t node_child_key(uint64_t parent_state, uint32_t k) { // same in oracle/rt_oracle.c
   return mix64(parent_state + (uint64_t)k * 0x9E3779B97F4A7C15ull);

@@ -165,6 +165,14 @@ struct RenderParams {
   // path mode: one node stack per WAVE in HBM, 64-byte records: node i of wave v at pool[(v * pool_cap + i) * 16 ...]  (rt_wavepath.h)
   float *pool;
   int32_t pool_cap;
+  // path mode: pixel samples a wave reserves from the call's queue per atomic, at least (it always reserves what its idle lanes
+  // ask for).  What a wave has reserved it must finish alone, so the last reservation of the slowest wave is the launch's tail:
+  // set by the host from the launch's size (rt_api.hip)
+  int32_t sample_chunk;
+  // path mode: fresh pixel samples a wave takes at most per iteration.  A wave tops up only when its whole stack holds fewer
+  // children than it has lanes, so the samples it takes then are finished together as one batch before the next are taken;
+  // the batch a wave is in when the queue runs dry is the launch's tail (rt_api.hip says how the host sets it)
+  int32_t fresh_max;
   // RT_FLAG_ACCEL_BVH: heap slots and leaf spheres staged in LDS; whether leaves use the (centre, r^2) form (rt_bvh.h)
   int32_t bvh_lds_nodes, bvh_lds_spheres, bvh_iso;
   // sizes of the lookup tables (k_render_path stages them in LDS when they are all small, rt_kernels.h)

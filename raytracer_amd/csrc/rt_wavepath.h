@@ -132,9 +132,9 @@ template <bool FAST, bool RUNS = false> struct WavePath {
     }
     const int n_pop = __popcll(__ballot(rem > 0 && incl <= 64));
     // fresh samples for the lanes the stack does not feed
-    int want = min(64 - take, n_free);
+    int want = min(min(64 - take, n_free), p.fresh_max);
     if (want > 0 && res_count == 0 && !exhausted) {
-      const unsigned long long chunk = (unsigned long long)SAMPLE_CHUNK * 64;
+      const unsigned long long chunk = (unsigned long long)max(p.sample_chunk, want);
       unsigned long long base = 0;
       if (lane == 0)
         base = atomicAdd(p.counters + 0, chunk);
