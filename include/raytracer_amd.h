@@ -187,8 +187,9 @@ typedef struct rt_render_cfg {
    * structure: World::ray_intersection is a linear scan).  Same hits, same tie rule, far fewer tests on
    * worlds with thousands of spheres; planes and CSG objects are still tested one by one.
    * RT_FLAG_VALU_ONLY: path mode on large worlds evaluates the sphere filter with vector-ALU instructions only
-   * (k_render_path_wide) instead of on the fp32 matrix cores (k_render_path_tile, the default: same arithmetic form,
-   * same fp32 lanes, fewer instructions).  For measurement: the configuration without any MFMA instruction.
+   * (k_render_path_wide) instead of on the matrix cores (k_render_path_tile, the default: the same two inner products per
+   * ray and sphere, binary32 operands split exactly into three bf16 parts, binary32 accumulation — same accuracy).  For
+   * measurement: the configuration without any MFMA instruction.
    */
   uint32_t flags;
 } rt_render_cfg;

@@ -1,5 +1,7 @@
 // rt_tile.h — the path kernel for large worlds of translation * uniform-scaling spheres: the closest-hit FILTER on the
-// matrix cores (v_mfma_f32_32x32x2_f32), 32 rays x 32 spheres per tile.
+// matrix cores, 32 rays x 32 spheres per tile.  Two builds of one kernel: the default multiplies on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, every binary32 operand split exactly into three bf16 parts: the second comment block below);
+// -DRT_TILE_BF16=0 keeps round 2's binary32 MFMAs (v_mfma_f32_32x32x2_f32: the first block) for A/B runs.
 #pragma once
 #include <type_traits>
 
@@ -9,6 +11,7 @@
 namespace rtd {
 
 // ---------------------------------------------------------------------------------------------
+// The filter as a matrix product, and its binary32 form (round 2).
 // Same pool, queue and finish as k_render_path_wide (rt_wide.h); what changes is who evaluates the filter
 //     b = O.u - C.u,   c = (O.O + k) - 2 O.C,   disc = b^2 - c          (u = D / |D|, k = C.C - r^2; see WideRayT<true>)
 // b and c are inner products of a per-ray vector with a per-sphere vector, so a block of rays against a block of spheres
