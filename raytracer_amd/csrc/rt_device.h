@@ -65,6 +65,11 @@ template <typename P> RT_DEV V3 hom_transposed_fast(P m, V3 n) {
              fmaf(m[2], n.x, fmaf(m[5], n.y, m[8] * n.z)));
 }
 
+// The same three for a transformation whose linear part is diagonal (Scene::all_diag): the terms hom_*_fast multiply by zero
+// are left out — bit for bit the same values, a zero result's sign aside.
+template <typename P> RT_DEV V3 diag_vec_fast(P m, V3 v) { return mk3(m[0] * v.x, m[4] * v.y, m[8] * v.z); }
+template <typename P> RT_DEV V3 diag_point_fast(P m, V3 p) { return mk3(fmaf(m[0], p.x, m[9]), fmaf(m[4], p.y, m[10]), fmaf(m[8], p.z, m[11])); }
+
 // x * 2^32 truncated toward zero — what (long long)((double)x * 4294967296.0) gives — without fp64: the integer part
 // and the fraction of |x| convert exactly.  |x| is clamped below 2^31 (oracle/rt_oracle.c clamps alike).
 RT_DEV long long to_fixed32(float x) {
@@ -276,14 +281,24 @@ RT_DEV void make_hit(const Scene &s, int shape, const Ray &ray_local, float t, V
 // The same record with fused transforms (FMA path tracer).
 RT_DEV void make_hit_fast(const Scene &s, int shape, const Ray &ray_world, float t, V3 &point, V3 &normal, V3 &local) {
   const float *inv = s.shape_inv + 12 * shape;
-  const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+  const bool diag = s.all_diag != 0; // uniform
+  V3 o, d;
+  if (diag)
+    o = diag_point_fast(inv, ray_world.o), d = diag_vec_fast(inv, ray_world.d);
+  else
+    o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
   const V3 p = mk3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z));
   V3 n = (s.shape_kind[shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
   const float sign = copysignf(1.0f, -fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z)));
   n = scale3(n, sign);
   local = p;
-  point = hom_point_fast(s.shape_fwd + 12 * shape, p);
-  normal = hom_transposed_fast(inv, n);
+  if (diag) {
+    point = diag_point_fast(s.shape_fwd + 12 * shape, p);
+    normal = diag_vec_fast(inv, n);
+  } else {
+    point = hom_point_fast(s.shape_fwd + 12 * shape, p);
+    normal = hom_transposed_fast(inv, n);
+  }
 }
 
 // Sphere::calculate_uv / Plane::calculate_uv — shapes.hpp:259-266, 365-367
@@ -504,6 +519,7 @@ RT_DEV bool csg_ray_intersection_fast(const Scene &s, const CsgTop &top, const R
 // stay in registers.
 template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const CsgTop &top, const Ray &ray_world, Hit &best) {
   const int n_leaves = top.leaf_end - top.leaf_begin;
+  const bool diag = s.all_diag != 0; // uniform: every transformation is translation * axis-aligned scaling
   float t_in[LMAX], t_out[LMAX], c0[LMAX], c1[LMAX]; // inside stretch (open); candidate hits (INF: none)
 #pragma unroll
   for (int j = 0; j < LMAX; ++j) {
@@ -512,7 +528,11 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
       const int shape = s.csg_leaf[top.leaf_begin + j].shape;
       const float *inv = s.shape_w2l + 12 * shape;
       if (s.shape_kind[shape] == RT_SHAPE_SPHERE) {
-        const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+        V3 o, d;
+        if (diag)
+          o = diag_point_fast(inv, ray_world.o), d = diag_vec_fast(inv, ray_world.d);
+        else
+          o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
         const float a = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
         const float b = fmaf(o.x, d.x, fmaf(o.y, d.y, o.z * d.z));
         const float c = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, -1.f)));
@@ -527,8 +547,13 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
             c1[j] = t2;
         }
       } else { // plane: inside where o.z + t d.z < 0 (shapes.hpp:353-358)
-        const float oz = fmaf(inv[6], ray_world.o.x, fmaf(inv[7], ray_world.o.y, fmaf(inv[8], ray_world.o.z, inv[11])));
-        const float dz = fmaf(inv[6], ray_world.d.x, fmaf(inv[7], ray_world.d.y, inv[8] * ray_world.d.z));
+        float oz, dz;
+        if (diag) {
+          oz = fmaf(inv[8], ray_world.o.z, inv[11]), dz = inv[8] * ray_world.d.z;
+        } else {
+          oz = fmaf(inv[6], ray_world.o.x, fmaf(inv[7], ray_world.o.y, fmaf(inv[8], ray_world.o.z, inv[11])));
+          dz = fmaf(inv[6], ray_world.d.x, fmaf(inv[7], ray_world.d.y, inv[8] * ray_world.d.z));
+        }
         const float t = -oz * __builtin_amdgcn_rcpf(dz);
         if (!are_close(dz, 0.f) && !(t < ray_world.tmin || t > ray_world.tmax)) // Plane::ray_intersection (shapes.hpp:329-338)
           c0[j] = t;
@@ -544,6 +569,38 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
   bool found = false;
   float best_t = 0.f;
   int best_leaf = -1;
+  if (top.tt == 2) { // uniform
+    // The intersection of all leaves (the host read it off the truth tables): the ray is inside the solid between the LAST
+    // entry T_in = max t_in and the FIRST exit T_out = min t_out, and those two boundaries are the only hits that can be valid —
+    // any other entry lies outside the leaf entered last, any other exit beyond the leaf left first.  Validity is the tables' rule,
+    // evaluated without them: the point is strictly inside every other leaf, i.e. L - 1 leaves contain it (a leaf does not
+    // contain its own boundary, nor does one whose boundary coincides: the strict compares of the general evaluator).
+    float T_in = -INF_F, E_in = INF_F, T_out = INF_F, E_out = INF_F; // E: the boundary as a candidate hit (INF: out of the ray's range)
+    int J_in = 0, J_out = 0;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+      if (j < n_leaves) {
+        const float e_in = c0[j] == t_in[j] ? c0[j] : INF_F;
+        const float e_out = c1[j] == t_out[j] ? c1[j] : (c0[j] == t_out[j] ? c0[j] : INF_F);
+        if (t_in[j] > T_in)
+          T_in = t_in[j], E_in = e_in, J_in = j;
+        if (t_out[j] < T_out)
+          T_out = t_out[j], E_out = e_out, J_out = j;
+      }
+    }
+    const auto leaves_containing = [&](float t) { // t finite
+      uint32_t n = 0;
+#pragma unroll
+      for (int i = 0; i < LMAX; ++i) // a leaf past n_leaves keeps t_in = +inf: never counted
+        n += (__float_as_uint(t_in[i] - t) & __float_as_uint(t - t_out[i])) >> 31;
+      return n;
+    };
+    const bool valid_in = E_in < INF_F && leaves_containing(E_in) == (uint32_t)(n_leaves - 1);
+    const bool valid_out = E_out < INF_F && leaves_containing(E_out) == (uint32_t)(n_leaves - 1);
+    found = valid_in || valid_out; // both valid: T_in lies inside the leaf left first, so E_in < E_out
+    best_t = valid_in ? E_in : E_out;
+    best_leaf = valid_in ? J_in : J_out;
+  } else {
 #pragma unroll
   for (int j = 0; j < LMAX; ++j) {
     if (j < n_leaves) {
@@ -572,10 +629,15 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
       }
     }
   }
+  }
   if (found) {
     const int best_shape = s.csg_leaf[top.leaf_begin + best_leaf].shape;
     const float *inv = s.shape_w2l + 12 * best_shape;
-    const V3 o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
+    V3 o, d;
+    if (diag)
+      o = diag_point_fast(inv, ray_world.o), d = diag_vec_fast(inv, ray_world.d);
+    else
+      o = hom_point_fast(inv, ray_world.o), d = hom_vec_fast(inv, ray_world.d);
     const V3 p = mk3(fmaf(best_t, d.x, o.x), fmaf(best_t, d.y, o.y), fmaf(best_t, d.z, o.z));
     V3 n = (s.shape_kind[best_shape] == RT_SHAPE_SPHERE) ? p : mk3(0.f, 0.f, 1.f);
     n = scale3(n, copysignf(1.0f, -fmaf(n.x, d.x, fmaf(n.y, d.y, n.z * d.z))));
@@ -583,8 +645,13 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
     best.shape = best_shape;
     best.object = top.object;
     best.local = p;
-    best.point = hom_point_fast(s.shape_l2w + 12 * best_shape, p);
-    best.normal = hom_transposed_fast(inv, n);
+    if (diag) {
+      best.point = diag_point_fast(s.shape_l2w + 12 * best_shape, p);
+      best.normal = diag_vec_fast(inv, n);
+    } else {
+      best.point = hom_point_fast(s.shape_l2w + 12 * best_shape, p);
+      best.normal = hom_transposed_fast(inv, n);
+    }
   }
   return found;
 }
@@ -709,14 +776,20 @@ RT_DEV TabRec load_tab_rec(const Scene &s, const ScanRec *recs, int i) {
   r.m0 = mp[0], r.m1 = mp[1], r.m2 = mp[2];
   return r;
 }
-RT_DEV void sphere_tab_test(const TabRec &r, const Ray &ray, Best &best) {
+RT_DEV void sphere_tab_test(const TabRec &r, const Ray &ray, Best &best, bool diag) {
   const float4 m0 = r.m0, m1 = r.m1, m2 = r.m2;
-  const float dx = fmaf(m0.x, ray.d.x, fmaf(m0.y, ray.d.y, m0.z * ray.d.z));
-  const float dy = fmaf(m0.w, ray.d.x, fmaf(m1.x, ray.d.y, m1.y * ray.d.z));
-  const float dz = fmaf(m1.z, ray.d.x, fmaf(m1.w, ray.d.y, m2.x * ray.d.z));
-  const float ox = fmaf(m0.x, ray.o.x, fmaf(m0.y, ray.o.y, fmaf(m0.z, ray.o.z, m2.y)));
-  const float oy = fmaf(m0.w, ray.o.x, fmaf(m1.x, ray.o.y, fmaf(m1.y, ray.o.z, m2.z)));
-  const float oz = fmaf(m1.z, ray.o.x, fmaf(m1.w, ray.o.y, fmaf(m2.x, ray.o.z, m2.w)));
+  float dx, dy, dz, ox, oy, oz;
+  if (diag) { // uniform (Scene::all_diag): the six terms below that multiply by zero are left out
+    dx = m0.x * ray.d.x, dy = m1.x * ray.d.y, dz = m2.x * ray.d.z;
+    ox = fmaf(m0.x, ray.o.x, m2.y), oy = fmaf(m1.x, ray.o.y, m2.z), oz = fmaf(m2.x, ray.o.z, m2.w);
+  } else {
+    dx = fmaf(m0.x, ray.d.x, fmaf(m0.y, ray.d.y, m0.z * ray.d.z));
+    dy = fmaf(m0.w, ray.d.x, fmaf(m1.x, ray.d.y, m1.y * ray.d.z));
+    dz = fmaf(m1.z, ray.d.x, fmaf(m1.w, ray.d.y, m2.x * ray.d.z));
+    ox = fmaf(m0.x, ray.o.x, fmaf(m0.y, ray.o.y, fmaf(m0.z, ray.o.z, m2.y)));
+    oy = fmaf(m0.w, ray.o.x, fmaf(m1.x, ray.o.y, fmaf(m1.y, ray.o.z, m2.z)));
+    oz = fmaf(m1.z, ray.o.x, fmaf(m1.w, ray.o.y, fmaf(m2.x, ray.o.z, m2.w)));
+  }
   const float a = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
   const float b = fmaf(ox, dx, fmaf(oy, dy, oz * dz));
   const float c = fmaf(ox, ox, fmaf(oy, oy, fmaf(oz, oz, -1.f)));
@@ -743,16 +816,17 @@ RT_DEV void scan_spheres_tab(const Scene &s, const Ray &ray, Best &best) {
   const int n = s.n_spheres;
   if (n <= 0)
     return;
+  const bool diag = s.all_diag != 0;
   TabRec a = load_tab_rec(s, s.spheres, 0); // the next record's reads are in flight while the lanes test the current one
   int i = 0;
   for (; i + 1 < n; i += 2) {
     const TabRec b = load_tab_rec(s, s.spheres, i + 1);
-    sphere_tab_test(a, ray, best);
+    sphere_tab_test(a, ray, best, diag);
     a = load_tab_rec(s, s.spheres, min(i + 2, n - 1));
-    sphere_tab_test(b, ray, best);
+    sphere_tab_test(b, ray, best, diag);
   }
   if (i < n)
-    sphere_tab_test(a, ray, best);
+    sphere_tab_test(a, ray, best, diag);
 }
 
 // The sphere a ray LEAVES is the one sphere whose test decides something systematic: a mirror ray (tmin = 1e-5) starts a
@@ -806,8 +880,13 @@ template <bool FAST, bool EXACT_RECORD = false, bool CSG = true, bool TT4 = fals
       ConstI32 ids = (ConstI32)(uintptr_t)&s.planes[i].object;
       const int object = ids[0], shape = ids[1];
       const float *m = s.shape_w2l + 12 * shape;
-      const float oz = fmaf(m[6], ray.o.x, fmaf(m[7], ray.o.y, fmaf(m[8], ray.o.z, m[11])));
-      const float dz = fmaf(m[6], ray.d.x, fmaf(m[7], ray.d.y, m[8] * ray.d.z));
+      float oz, dz;
+      if (s.all_diag) { // uniform
+        oz = fmaf(m[8], ray.o.z, m[11]), dz = m[8] * ray.d.z;
+      } else {
+        oz = fmaf(m[6], ray.o.x, fmaf(m[7], ray.o.y, fmaf(m[8], ray.o.z, m[11])));
+        dz = fmaf(m[6], ray.d.x, fmaf(m[7], ray.d.y, m[8] * ray.d.z));
+      }
       const float t = -oz * __builtin_amdgcn_rcpf(dz);
       const bool hit = !are_close(dz, 0.f) && !(t < ray.tmin || t > ray.tmax);
       if (hit && (t < best.t || (t == best.t && object < best.object))) {

@@ -377,6 +377,16 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       leaf_tt[static_cast<size_t>(top.leaf_begin + j)] = table;
     }
     top.tt = 1;
+    // The tree is the intersection of all its leaves when a boundary hit of leaf j is valid exactly where every OTHER leaf
+    // contains the point: one bit per table.  Then the evaluator needs two candidates, not 2 L (rt_device.h, CsgTop::tt == 2).
+    bool all_of = n_leaves >= 2;
+    const uint32_t full = (1u << n_leaves) - 1u;
+    for (int j = 0; j < n_leaves && all_of; ++j)
+      for (uint32_t mask = 0; mask <= full && all_of; ++mask)
+        if (!(mask & (1u << j))) // the evaluator never sets a leaf's own bit
+          all_of = ((leaf_tt[static_cast<size_t>(top.leaf_begin + j)] >> mask) & 1ull) == (mask == (full & ~(1u << j)) ? 1ull : 0ull);
+    if (all_of)
+      top.tt = 2;
   }
   // world <-> local transforms of every shape with its CSG ancestors folded in (computed in binary64, rounded once)
   std::vector<float> shape_w2l(d->shape_inv, d->shape_inv + 12 * static_cast<size_t>(d->n_shapes));
@@ -621,6 +631,15 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   S.n_objects = static_cast<int32_t>(d->n_objects);
   UP(upload(sc, d->shape_fwd, 12 * static_cast<size_t>(d->n_shapes), &S.shape_fwd));
   UP(upload(sc, d->shape_inv, 12 * static_cast<size_t>(d->n_shapes), &S.shape_inv));
+  {
+    bool diag = true;
+    const float *tables[4] = {d->shape_fwd, d->shape_inv, shape_w2l.data(), shape_l2w.data()};
+    for (const float *t : tables)
+      for (size_t i = 0; i < static_cast<size_t>(d->n_shapes) && diag; ++i)
+        for (int k : {1, 2, 3, 5, 6, 7})
+          diag = diag && t[12 * i + static_cast<size_t>(k)] == 0.f;
+    S.all_diag = diag ? 1 : 0;
+  }
   UP(upload(sc, shape_w2l, &S.shape_w2l));
   UP(upload(sc, shape_l2w, &S.shape_l2w));
   UP(upload(sc, d->shape_kind, d->n_shapes, &S.shape_kind));

@@ -24,7 +24,8 @@ struct CsgTop {        // one top-level CSGObject
   int32_t object;      // index in World::objects
   int32_t leaf_begin;  // range in csg_leaf[]
   int32_t leaf_end;
-  int32_t tt;          // 1: the tree has at most CSG_TT_MAX_LEAVES leaves and csg_leaf_tt[] holds their truth tables
+  int32_t tt;          // 1: the tree has at most CSG_TT_MAX_LEAVES leaves and csg_leaf_tt[] holds their truth tables;
+                       // 2: ... and the tables say the tree is the intersection of all its leaves
 };
 // Truth-table form of the validity rule (FMA path kernels, trees of up to 6 leaves): a boundary hit on leaf l is kept iff
 // every ancestor's rule accepts it, and each rule looks only at "is the point inside the sibling subtree", a boolean
@@ -91,6 +92,11 @@ struct Scene {
   //    a place past n_wide holds 0 0 0 and k = +inf (never hit)
   const float *wide_tiles; int32_t n_wide_tiles;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
+  // every transformation of the world (shapes, CSG leaves with their ancestors folded in) is translation * axis-aligned scaling:
+  // all off-diagonal entries of shape_fwd / shape_inv / shape_w2l / shape_l2w are zero.  True for every sample scene of the
+  // reference and for the synthetic worlds; the small-world FMA kernel then multiplies by the three diagonal entries only
+  // (6 instructions per transformed ray instead of 21: the same bits, the zero terms add nothing)
+  int32_t all_diag;
   // RT_FLAG_ACCEL_BVH (rt_bvh.h): heap of n_bvh_nodes slots (0: no hierarchy); the spheres inside it regrouped by
   // leaf (records, and centre + r^2 when spheres_all_iso); the spheres too big for it, scanned linearly first
   const BvhNode *bvh; int32_t n_bvh_nodes;
