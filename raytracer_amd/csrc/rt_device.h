@@ -600,6 +600,20 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
     found = valid_in || valid_out; // both valid: T_in lies inside the leaf left first, so E_in < E_out
     best_t = valid_in ? E_in : E_out;
     best_leaf = valid_in ? J_in : J_out;
+  } else if (top.tt == 3) { // uniform
+    // The union of all leaves as the reference evaluates it: every boundary hit is valid, so the first hit is the smallest
+    // candidate — same visiting order and tie rules as the table loop below (a later leaf takes a tie, a leaf's second root does not).
+    best_t = INF_F;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+      if (j < n_leaves) {
+        const bool first = c0[j] <= best_t && c0[j] < INF_F;
+        best_t = first ? c0[j] : best_t, best_leaf = first ? j : best_leaf;
+        const bool second = c1[j] < INF_F && (first ? c1[j] < best_t : c1[j] <= best_t);
+        best_t = second ? c1[j] : best_t, best_leaf = second ? j : best_leaf;
+      }
+    }
+    found = best_leaf >= 0;
   } else {
 #pragma unroll
   for (int j = 0; j < LMAX; ++j) {

@@ -387,6 +387,15 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
           all_of = ((leaf_tt[static_cast<size_t>(top.leaf_begin + j)] >> mask) & 1ull) == (mask == (full & ~(1u << j)) ? 1ull : 0ull);
     if (all_of)
       top.tt = 2;
+    // ... and the union of all its leaves when every boundary hit is valid whatever the other leaves say (the reference keeps
+    // every hit of a union, inner ones too: shapes.hpp:460-490): all tables all ones.  Then the first hit is the smallest candidate.
+    bool any_of = n_leaves >= 2 && !all_of;
+    for (int j = 0; j < n_leaves && any_of; ++j)
+      for (uint32_t mask = 0; mask <= full && any_of; ++mask)
+        if (!(mask & (1u << j)))
+          any_of = ((leaf_tt[static_cast<size_t>(top.leaf_begin + j)] >> mask) & 1ull) != 0ull;
+    if (any_of)
+      top.tt = 3;
   }
   // world <-> local transforms of every shape with its CSG ancestors folded in (computed in binary64, rounded once)
   std::vector<float> shape_w2l(d->shape_inv, d->shape_inv + 12 * static_cast<size_t>(d->n_shapes));

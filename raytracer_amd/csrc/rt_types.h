@@ -25,7 +25,7 @@ struct CsgTop {        // one top-level CSGObject
   int32_t leaf_begin;  // range in csg_leaf[]
   int32_t leaf_end;
   int32_t tt;          // 1: the tree has at most CSG_TT_MAX_LEAVES leaves and csg_leaf_tt[] holds their truth tables;
-                       // 2: ... and the tables say the tree is the intersection of all its leaves
+                       // 2: ... and the tables say the tree is the intersection of all its leaves; 3: their union (every hit valid)
 };
 // Truth-table form of the validity rule (FMA path kernels, trees of up to 6 leaves): a boundary hit on leaf l is kept iff
 // every ancestor's rule accepts it, and each rule looks only at "is the point inside the sibling subtree", a boolean

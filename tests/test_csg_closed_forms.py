@@ -1,7 +1,8 @@
 """CSG trees that are the intersection of all their leaves (samples/csg_example.txt is one): the fused path kernels evaluate
 them in closed form — the ray is inside the solid between the last entry and the first exit, and only those two boundaries can
-be valid hits (rt_device.h, CsgTop::tt == 2) — instead of testing all 2 L boundary hits against the truth tables.  The host
-decides from the truth tables, so a tree with one other operation must keep the general evaluator.
+be valid hits (rt_device.h, CsgTop::tt == 2) — instead of testing all 2 L boundary hits against the truth tables.  Trees that are
+the union of all their leaves (tt == 3: the reference keeps every hit of a union) take the smallest candidate.  The host decides
+from the truth tables, so a tree with one other operation must keep the general evaluator.
 
 Every leaf has its own emitting material and max_depth is 0, so a path-mode pixel is the emission of the leaf whose boundary
 the camera ray hits first: the image is the table of winners, free of Monte-Carlo noise.  The fused kernel must name the winners
@@ -56,6 +57,15 @@ def build(kind):
         leaves = [b.sphere(compose(translation([0, 0, 0])), mat(0), True), b.sphere(compose(translation([0, 0, 0])), mat(1), True),
                   b.plane(compose(translation([0, 0, 0.3])), mat(2), True)]
         ops = ["intersection"] * 2
+    elif kind == "union":  # every hit of every leaf is valid (shapes.hpp:460-490): the first one wins
+        leaves = [b.sphere(compose(translation([0, 0.5, 0])), mat(0), True), b.sphere(compose(translation([0, -0.5, 0.2]), scaling([0.9, 0.9, 0.9])), mat(1), True),
+                  b.sphere(compose(translation([-0.5, 0, 0.6]), scaling([0.5, 0.5, 0.5])), mat(2), True),
+                  b.sphere(compose(translation([0.2, 0, -0.5]), rotation_z(degs_to_rads(40)), scaling([1.1, 0.6, 0.5])), mat(3), True)]
+        ops = ["union"] * 3
+    elif kind == "union_of_intersection":  # (a and b) or c: neither closed form applies
+        leaves = [b.sphere(compose(translation([0, 0.3, 0])), mat(0), True), b.sphere(compose(translation([0, -0.5, 0.1])), mat(1), True),
+                  b.sphere(compose(translation([-0.3, 0, 0.8]), scaling([0.6, 0.6, 0.6])), mat(2), True)]
+        ops = ["intersection", "union"]
     else:  # "mixed": one difference among the intersections — NOT a pure intersection, the general evaluator must run
         leaves = [b.sphere(compose(translation([0, 0.2, 0])), mat(0), True), b.sphere(compose(translation([0, -0.6, 0.1])), mat(1), True),
                   b.sphere(compose(translation([-0.7, 0, 0.3]), scaling([0.6, 0.6, 0.6])), mat(2), True), b.plane(compose(translation([0, 0, 0.6])), mat(3), True)]
@@ -66,7 +76,7 @@ def build(kind):
     return b.build()
 
 
-@pytest.mark.parametrize("kind", ["axis_aligned", "rotated", "six_leaves", "coincident", "mixed"])
+@pytest.mark.parametrize("kind", ["axis_aligned", "rotated", "six_leaves", "coincident", "mixed", "union", "union_of_intersection"])
 def test_fused_evaluator_names_the_exact_kernels_winners(kind):
     from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
     scene = build(kind)
