@@ -5,7 +5,7 @@ the World + frame) and a frame on the resident World (fire_all_rays alone: flatt
 beside the kernel time of the same frame.  The reference's sample files do not travel to the GPU box: the scene text is
 written back from the flattened fixtures in tests/golden/ (raytracer_amd/scene_text.py; same objects, same order).
 
-    python scripts/cpp_end_to_end.py > profiles/r2/cpp_end_to_end.jsonl
+    python scripts/cpp_end_to_end.py > profiles/r3/cpp_end_to_end.jsonl
 """
 import json
 import os
