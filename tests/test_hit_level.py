@@ -95,7 +95,7 @@ def within_rounding(geo, obj_a, obj_b, o, d):
     return ts[0] is not None and ts[1] is not None and abs(ts[0] - ts[1]) <= 1e-5 * abs(ts[1])
 
 
-@pytest.mark.parametrize("n", [600, 4000])
+@pytest.mark.parametrize("n", [600, 1000, 2500, 4000])  # 19, 32, 79 and 125 sphere tiles: W = 2 with a partial pass, W = 2 full, W = 4 with an uneven last pass, W = 4
 def test_fast_scans_pick_the_reference_winner(n):
     scene, geo = id_world(n)
     kw = dict(n_rays=1, roulette=5, max_depth=1, seq_number=3)
