@@ -21,7 +21,8 @@ before anything touches the GPU) and relays rank 0's line.  Scene and buffers ar
 
 At N = 1 the line also carries `configs`: BASELINE.json's configs measured in the same run — C1 (onoff), C2 (flat and
 pointlight), C3, C4 (path on the reference's sample scenes, full size), the full N=512 frame (round 2's default) with and
-without the matrix-core filter — each with its kernel, ray count, kernel ms (HIP events of the same launch) and roofline block.
+without the matrix-core filter, and the headline's share 0 without it — each with its kernel, ray count, kernel ms (HIP events
+of the same launch) and roofline block.
 configs[4] (3840x2160) is four times the headline frame: 64 shares of this cost.
 
 Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
@@ -286,6 +287,11 @@ def measure_configs(device, log):
     # brute-force ray x sphere filter turned out to be one): the vector-ALU filter kernel.
     run("N512-valu-only", "the same frame with RT_FLAG_VALU_ONLY: the sphere filter on the vector ALU, no matrix-core instruction",
         small, RenderMode("path", valu_only=True), 1920, 1080, 4, reps=1)
+    # The headline's own share 0 with the filter in binary32 on the vector ALU: the figure to hold against `value` if the bf16-split
+    # matrix filter is to be discounted (it loses no accuracy — DESIGN.md 4.4 — but it is not binary32 arithmetic instruction by instruction).
+    big = synthetic_scene(4096)[0]
+    run("N4096-share-valu-only", "the headline's share 0 (1/16 of the 4096-sphere 1920x1080 AA=4 frame) with RT_FLAG_VALU_ONLY: binary32 filter on the vector ALU, no matrix-core instruction",
+        big, RenderMode("path", valu_only=True), 1920, 1080, 4, rows=RowBands.cyclic(1080, 0, 16, 1), reps=1)
     return recs
 
 
