@@ -520,7 +520,7 @@ RT_DEV bool csg_ray_intersection_fast(const Scene &s, const CsgTop &top, const R
 template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const CsgTop &top, const Ray &ray_world, Hit &best) {
   const int n_leaves = top.leaf_end - top.leaf_begin;
   const bool diag = s.all_diag != 0; // uniform: every transformation is translation * axis-aligned scaling
-  float t_in[LMAX], t_out[LMAX], c0[LMAX], c1[LMAX]; // inside stretch (open); candidate hits (INF: none)
+  float t_in[LMAX], t_out[LMAX], c0[LMAX], c1[LMAX]; // inside stretch (open); its two ends as candidate hits (INF: not in the ray's range)
 #pragma unroll
   for (int j = 0; j < LMAX; ++j) {
     t_in[j] = INF_F, t_out[j] = -INF_F, c0[j] = INF_F, c1[j] = INF_F;
@@ -555,12 +555,11 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
           dz = fmaf(inv[6], ray_world.d.x, fmaf(inv[7], ray_world.d.y, inv[8] * ray_world.d.z));
         }
         const float t = -oz * __builtin_amdgcn_rcpf(dz);
-        if (!are_close(dz, 0.f) && !(t < ray_world.tmin || t > ray_world.tmax)) // Plane::ray_intersection (shapes.hpp:329-338)
-          c0[j] = t;
-        if (dz > 0.f)
-          t_in[j] = -INF_F, t_out[j] = t;
+        const float cand = !are_close(dz, 0.f) && !(t < ray_world.tmin || t > ray_world.tmax) ? t : INF_F; // Plane::ray_intersection (shapes.hpp:329-338)
+        if (dz > 0.f) // the ray leaves the half-space at t: c0 is a leaf's ENTRY as a candidate hit, c1 its EXIT (as for a sphere's two roots)
+          t_in[j] = -INF_F, t_out[j] = t, c1[j] = cand;
         else if (dz < 0.f)
-          t_in[j] = t, t_out[j] = INF_F;
+          t_in[j] = t, t_out[j] = INF_F, c0[j] = cand;
         else if (oz < 0.f)
           t_in[j] = -INF_F, t_out[j] = INF_F;
       }
@@ -580,12 +579,10 @@ template <int LMAX> RT_DEV bool csg_ray_intersection_tt(const Scene &s, const Cs
 #pragma unroll
     for (int j = 0; j < LMAX; ++j) {
       if (j < n_leaves) {
-        const float e_in = c0[j] == t_in[j] ? c0[j] : INF_F;
-        const float e_out = c1[j] == t_out[j] ? c1[j] : (c0[j] == t_out[j] ? c0[j] : INF_F);
-        if (t_in[j] > T_in)
-          T_in = t_in[j], E_in = e_in, J_in = j;
+        if (t_in[j] > T_in) // c0 / c1: the leaf's entry / exit as a candidate hit (INF: out of the ray's range)
+          T_in = t_in[j], E_in = c0[j], J_in = j;
         if (t_out[j] < T_out)
-          T_out = t_out[j], E_out = e_out, J_out = j;
+          T_out = t_out[j], E_out = c1[j], J_out = j;
       }
     }
     const auto leaves_containing = [&](float t) { // t finite
