@@ -65,6 +65,7 @@ enum { RT_RNG_PER_NODE_STREAMS = 0, RT_RNG_SERIAL_REFERENCE = 1 };
 #define RT_FLAG_OBJECT_SPACE_SPHERES 2u
 #define RT_FLAG_ACCEL_BVH 4u
 #define RT_FLAG_VALU_ONLY 8u
+#define RT_FLAG_SCAN_ALL_TILES 16u
 
 /* Limits of the device CSG evaluator (fixed-capacity, no heap). */
 #define RT_MAX_CSG_DEPTH 8    /* nesting depth of CSG nodes below one top-level object */

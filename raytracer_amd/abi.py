@@ -22,6 +22,7 @@ RT_FLAG_EXACT_ARITHMETIC = 1
 RT_FLAG_OBJECT_SPACE_SPHERES = 2
 RT_FLAG_ACCEL_BVH = 4
 RT_FLAG_VALU_ONLY = 8
+RT_FLAG_SCAN_ALL_TILES = 16
 RT_MAX_CSG_DEPTH = 8
 RT_MAX_CSG_LEAVES = 32
 RT_NOALLOC_SCRATCH_BYTES = 128 * 1024 * 1024

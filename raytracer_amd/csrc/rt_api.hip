@@ -102,6 +102,7 @@ const void *rt_wide_kernel_iso(int k, int waves);
 const void *rt_wide_kernel_gen(int k, int waves);
 const void *rt_tile_kernel(int waves, bool csg); // rt_wide_tile.hip: k_render_path_tile<S, W, CSG>
 int rt_tile_s();                                // its S: sphere tiles per wave and pass
+const void *rt_tile_cull_kernel(bool csg);      // rt_wide_tile.hip: k_render_path_tile_cull<4, CSG>
 // From how many register spheres on the large-world kernels replace the per-lane scan of the small-world kernel.  Measured
 // with the tile kernel (synthetic worlds, 960x540 AA=4, frame ms tile | per-lane): 16 spheres 17.2 | 9.8, 24: 20.5 | 19.2,
 // 32: 26.6 | 27.5, 48: 26.2 | 27.5, 64: 25.7 | 26.6 — one full tile of 32 is the break-even.
@@ -342,6 +343,15 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
         path_kernel = rt_tile_kernel(waves, sc->dev.n_csg_tops > 0);
         nodes_per_level = 64, stacks_per_block = waves, node_words = rtd::WAVE_NODE_WORDS; // one wave pool per wave (rt_wavepath.h)
         std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile<S=%d,W=%d%s>", tile_s, waves, RT_TILE_BF16 ? ",BF16x3" : "");
+        // Worlds of many tiles: the spheres as spatial clusters, a tile multiplied only with the rays that meet its bound
+        // (rt_tile_cull.h) — the same keys, hence the same frame; RT_FLAG_SCAN_ALL_TILES keeps every ray on every tile.
+        if (sc->dev.n_cull_tiles > 0 && !(cfg->flags & RT_FLAG_SCAN_ALL_TILES) && rt_tile_cull_kernel(false)) {
+          waves = 4;
+          block = 64u * static_cast<unsigned>(waves);
+          path_kernel = rt_tile_cull_kernel(sc->dev.n_csg_tops > 0);
+          stacks_per_block = waves;
+          std::snprintf(kernel_name, sizeof kernel_name, "k_render_path_tile_cull<W=%d,BF16x3>", waves);
+        }
       }
     }
     int per_cu = 0;
@@ -444,6 +454,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera *cam, const rt_render_cfg *c
     if (c[7])
       std::fprintf(stderr, "[rt phases] blocks*iters=%llu rays/iter=%.1f cycles/iter: queue=%.0f scan=%.0f shade=%.0f (100 MHz ticks x?)\n", c[7],
                    double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]));
+    if (c[7] && c[13])
+      std::fprintf(stderr, "[rt cull] per wave iteration: rays=%.1f queue=%.0f level1(+wait)=%.0f level2=%.0f finish+shade=%.0f ticks; clusters=%.1f blocks=%.2f pairs=%.1f -> clusters met per ray=%.2f\n",
+                   double(c[8]) / double(c[7]), double(c[4]) / double(c[7]), double(c[5]) / double(c[7]), double(c[6]) / double(c[7]), double(c[11]) / double(c[7]),
+                   double(c[13]) / double(c[7]), double(c[10]) / double(c[7]), double(c[12]) / double(c[7]), double(c[12]) / double(std::max<unsigned long long>(c[8], 1)));
     if (c[7] && c[9])
       std::fprintf(stderr, "[rt phases] of shade: finish (lane spheres, planes, exact record) = %.0f\n", double(c[9]) / double(c[7]));
 #endif

@@ -491,6 +491,8 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       wide_rmin2 = std::min(wide_rmin2, r * r);
     }
   std::vector<float> wide_tiles; // rt_tile.h: the MFMA's A operands
+  std::vector<float> cull_tiles, cull_bounds; // rt_tile_cull.h
+  std::vector<int32_t> cull_rank, cull_pos;
   const size_t n_wide_tiles = all_iso ? (wide_recs.size() + 31) / 32 : 0;
   wide_tiles.resize(n_wide_tiles * rtd::RT_TILE_WORDS);
 #if RT_TILE_BF16
@@ -515,29 +517,103 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     part[2] = bf16_rn(r);
   };
   static const int part_of_slot[6] = {0, 0, 0, 1, 1, 2};
+  // row i of the tile whose RT_TILE_WORDS words start at `tile`: the operand words of the sphere (centre v[0..2], k = v[3])
+  auto pack_tile_row = [&](float *tile, size_t i, const float v[4]) {
+    uint32_t parts[4][3];
+    for (int q = 0; q < 4; ++q)
+      split3(v[q], parts[q]);
+    uint32_t slot[32] = {0};
+    for (int q = 0; q < 3; ++q)
+      for (int j = 0; j < 6; ++j)
+        slot[6 * q + j] = parts[q][part_of_slot[j]];
+    slot[18] = slot[19] = slot[20] = 0x3f80u; // 1
+    slot[21] = parts[3][0], slot[22] = parts[3][1], slot[23] = parts[3][2];
+    for (size_t c = 0; c < 2; ++c)
+      for (size_t half = 0; half < 2; ++half)
+        for (size_t w = 0; w < 4; ++w) {
+          const size_t s0 = 16 * c + 8 * half + 2 * w;
+          const uint32_t word = slot[s0] | (slot[s0 + 1] << 16);
+          std::memcpy(&tile[(c * 64 + half * 32 + i) * 4 + w], &word, 4);
+        }
+  };
+  static const float never_hit[4] = {0.f, 0.f, 0.f, 1e30f}; // a place past the last sphere: c = 1e30
   for (size_t t = 0; t < n_wide_tiles; ++t)
     for (size_t i = 0; i < 32; ++i) {
       const size_t k = t * 32 + i;
-      const bool valid = k < wide_recs.size();
-      const float v[4] = {valid ? wide_iso[4 * k] : 0.f, valid ? wide_iso[4 * k + 1] : 0.f, valid ? wide_iso[4 * k + 2] : 0.f,
-                          valid ? wide_iso[4 * k + 3] : 1e30f}; // a place past the last sphere: c = 1e30, never hit
-      uint32_t parts[4][3];
-      for (int q = 0; q < 4; ++q)
-        split3(v[q], parts[q]);
-      uint32_t slot[32] = {0};
-      for (int q = 0; q < 3; ++q)
-        for (int j = 0; j < 6; ++j)
-          slot[6 * q + j] = parts[q][part_of_slot[j]];
-      slot[18] = slot[19] = slot[20] = 0x3f80u; // 1
-      slot[21] = parts[3][0], slot[22] = parts[3][1], slot[23] = parts[3][2];
-      for (size_t c = 0; c < 2; ++c)
-        for (size_t half = 0; half < 2; ++half)
-          for (size_t w = 0; w < 4; ++w) {
-            const size_t s0 = 16 * c + 8 * half + 2 * w;
-            const uint32_t word = slot[s0] | (slot[s0 + 1] << 16);
-            std::memcpy(&wide_tiles[t * rtd::RT_TILE_WORDS + (c * 64 + half * 32 + i) * 4 + w], &word, 4);
-          }
+      pack_tile_row(&wide_tiles[t * rtd::RT_TILE_WORDS], i, k < wide_recs.size() ? &wide_iso[4 * k] : never_hit);
     }
+  // The same spheres once more as spatial CLUSTERS of 32 with a bounding sphere each (rt_tile_cull.h): a k-d split of the centres
+  // at multiples of 32 along the widest axis, so that every cluster but the last is full.  cull_rank maps a cluster position back
+  // to the position in wide_recs (object order: what a hit's key carries, so that equal distances resolve as the reference's
+  // strict `<` does), cull_pos is the inverse (the sphere a ray leaves is excluded by position).
+  if (n_wide_tiles >= RT_CULL_MIN_TILES) {
+    const size_t n = wide_recs.size();
+    std::vector<int32_t> order(n);
+    for (size_t k = 0; k < n; ++k)
+      order[k] = static_cast<int32_t>(k);
+    std::vector<std::pair<size_t, size_t>> todo{{0, n}};
+    while (!todo.empty()) {
+      const auto [b, e] = todo.back();
+      todo.pop_back();
+      if (e - b <= 32)
+        continue;
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (size_t k = b; k < e; ++k)
+        for (int a = 0; a < 3; ++a)
+          lo[a] = std::min(lo[a], wide_iso[4 * order[k] + a]), hi[a] = std::max(hi[a], wide_iso[4 * order[k] + a]);
+      int axis = 0;
+      for (int a = 1; a < 3; ++a)
+        if (hi[a] - lo[a] > hi[axis] - lo[axis])
+          axis = a;
+      const size_t tiles = (e - b + 31) / 32, mid = b + 32 * ((tiles + 1) / 2);
+      std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](int32_t x, int32_t y) {
+        const float fx = wide_iso[4 * x + axis], fy = wide_iso[4 * y + axis];
+        return fx < fy || (fx == fy && x < y);
+      });
+      todo.push_back({b, mid}), todo.push_back({mid, e});
+    }
+    for (size_t b = 0; b < n; b += 32) // within a cluster in object order: equal distances resolve by row (rt_tile_cull.h)
+      std::sort(order.begin() + b, order.begin() + std::min(b + 32, n));
+    cull_rank.assign(n_wide_tiles * 32, -1);
+    cull_pos.assign(n, -1);
+    cull_tiles.resize(n_wide_tiles * rtd::RT_TILE_WORDS);
+    constexpr size_t CW = rtd::RT_CULL_W;
+    const size_t n_groups = (n_wide_tiles + 32 * CW - 1) / (32 * CW) * CW; // bound tiles: one per group of 32 CW clusters and wave
+    cull_bounds.resize(n_groups * rtd::RT_TILE_WORDS);
+    for (size_t g = 0; g < n_groups; ++g)
+      for (size_t i = 0; i < 32; ++i)
+        pack_tile_row(&cull_bounds[g * rtd::RT_TILE_WORDS], i, never_hit);
+    for (size_t t = 0; t < n_wide_tiles; ++t) {
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      auto radius_of = [&](size_t k) { return std::fabs(static_cast<double>(d->shape_fwd[12 * static_cast<size_t>(wide_recs[k].shape)])); };
+      for (size_t i = 0; i < 32; ++i) {
+        const size_t pos = t * 32 + i;
+        if (pos >= n) {
+          pack_tile_row(&cull_tiles[t * rtd::RT_TILE_WORDS], i, never_hit);
+          continue;
+        }
+        const size_t k = static_cast<size_t>(order[pos]);
+        cull_rank[pos] = static_cast<int32_t>(k), cull_pos[k] = static_cast<int32_t>(pos);
+        pack_tile_row(&cull_tiles[t * rtd::RT_TILE_WORDS], i, &wide_iso[4 * k]);
+        for (int a = 0; a < 3; ++a)
+          lo[a] = std::min(lo[a], wide_iso[4 * k + a] - radius_of(k)), hi[a] = std::max(hi[a], wide_iso[4 * k + a] + radius_of(k));
+      }
+      // bounding sphere about the (rounded) middle of the cluster's box; its radius^2 is inflated by more than the filter's
+      // rounding can move either of the level-1 decisions (world_filter_ok: that error is below 0.05 r_min^2 wherever this kernel runs)
+      const float centre[3] = {static_cast<float>(0.5 * (lo[0] + hi[0])), static_cast<float>(0.5 * (lo[1] + hi[1])), static_cast<float>(0.5 * (lo[2] + hi[2]))};
+      double reach = 0.0;
+      for (size_t i = 0; i < 32 && t * 32 + i < n; ++i) {
+        const size_t k = static_cast<size_t>(order[t * 32 + i]);
+        const double dx = wide_iso[4 * k] - double(centre[0]), dy = wide_iso[4 * k + 1] - double(centre[1]), dz = wide_iso[4 * k + 2] - double(centre[2]);
+        reach = std::max(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + radius_of(k));
+      }
+      const double r2 = reach * reach * (1.0 + 1.0 / 1024.0) + 0.5 * wide_rmin2;
+      const double cc = double(centre[0]) * centre[0] + double(centre[1]) * centre[1] + double(centre[2]) * centre[2];
+      const float v[4] = {centre[0], centre[1], centre[2], static_cast<float>(cc - r2)};
+      // cluster t = 32 CW g + CW i + w is row i of bound tile g CW + w: a wave's 32 clusters of a group are spread over the group's space
+      pack_tile_row(&cull_bounds[(t / (32 * CW) * CW + t % CW) * rtd::RT_TILE_WORDS], t % (32 * CW) / CW, v);
+    }
+  }
 #else
   for (size_t t = 0; t < n_wide_tiles; ++t)
     for (size_t l = 0; l < 64; ++l) {
@@ -628,6 +704,11 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
   UP(upload(sc, wide_lane, &S.wide_lane));
   UP(upload(sc, wide_tiles, &S.wide_tiles));
   S.n_wide_tiles = static_cast<int32_t>(n_wide_tiles);
+  UP(upload(sc, cull_tiles, &S.cull_tiles));
+  UP(upload(sc, cull_bounds, &S.cull_bounds));
+  UP(upload(sc, cull_rank, &S.cull_rank));
+  UP(upload(sc, cull_pos, &S.cull_pos));
+  S.n_cull_tiles = static_cast<int32_t>(cull_tiles.size() / rtd::RT_TILE_WORDS);
   sc->wide_reach = wide_reach, sc->wide_rmin2 = wide_rmin2;
   S.n_wide = static_cast<int32_t>(wide_recs.size());
   S.wide_rows = (S.n_wide + 63) / 64;

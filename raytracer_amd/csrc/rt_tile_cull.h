@@ -1,0 +1,317 @@
+// rt_tile_cull.h — the tile kernel (rt_tile.h, bf16 build) for worlds of many tiles: a sphere tile is multiplied only with the
+// rays whose line meets the tile's bounding sphere.
+//
+// k_render_path_tile tests every queued ray against every sphere: 128 tile products per 32 rays at N = 4096, of which a ray's
+// line meets a sphere in a handful.  Here the host also keeps the register spheres as spatial CLUSTERS of 32 (a k-d split of
+// the centres, rt_scene.hip) with one bounding sphere per cluster, and an iteration of a workgroup runs per GROUP of 32 clusters:
+//   level 1  every wave multiplies its own rays with the group's 32 BOUNDS — the very products of the sphere filter, a bound is a
+//            sphere — and leaves per ray a 32-bit word in LDS: bit t set if the ray's line meets bound t with the far root beyond
+//            the ray's tmin (a cluster wholly behind the ray cannot hold its hit).
+//   level 2  every wave takes its share of the group's clusters; per cluster it collects the rays of the WHOLE workgroup whose bit
+//            is set (one ballot per 64 rays, the slot numbers compacted into a byte list in LDS) and multiplies the cluster's tile
+//            with those rays only, 32 at a time — products, candidates and keys exactly as k_render_path_tile forms them.
+// The result is the same: a ray whose line misses a cluster's bound misses its spheres, a product element does not depend on
+// which other rays share its block, so every (ray, sphere) pair that could give a candidate is evaluated with the same bits and
+// the keys' minimum is the same — the frames are bit-identical to the unculled kernel's (tests/test_tile_cull.py).  A key
+// carries the sphere's position in OBJECT order (Scene::cull_rank), so equal distances still resolve as the reference's `<`.
+// The bounds are inflated by more than the filter's rounding can move either level-1 decision (rt_scene.hip).
+//
+// Work per iteration of a 256-ray workgroup at N = 4096 (128 clusters, a ray meets 8 of them on average): 4 x 8 bound products
+// + 128 x about 1.2 blocks, against 128 x 8 before.
+#pragma once
+#include "rt_tile.h"
+
+namespace rtd {
+
+// the two products of one tile (a0 | a1: its operand words for K chunks 0 | 1) with one block of 32 rays
+RT_DEV void tile_products_bf16(const float4 &a0, const float4 &a1, const float4 &qb0, const float4 &qb1, const float4 &qc0, const float4 &qc1,
+                               f32x16 &b, f32x16 &c) {
+  union Op {
+    bf16x8 v;
+    float f[4];
+  };
+  auto op = [](const float4 &q) {
+    Op o;
+    o.f[0] = q.x, o.f[1] = q.y, o.f[2] = q.z, o.f[3] = q.w;
+    return o.v;
+  };
+  b = f32x16{0}, c = f32x16{0};
+  b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a0), op(qb0), b, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a0), op(qc0), c, 0, 0, 0);
+  b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a1), op(qb1), b, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a1), op(qc1), c, 0, 0, 0);
+}
+
+template <int W, bool CSG>
+__global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(Scene s, RenderParams p) {
+  constexpr int T = 64 * W;
+  static_assert(T <= 256 && W == RT_CULL_W, "ray slots are listed as bytes; the host deals the clusters to RT_CULL_W waves");
+  __shared__ TileRayBf q_ray[T];
+  __shared__ unsigned long long q_key[T];
+  __shared__ uint8_t q_list[W][T];   // per wave: the slots of the rays it multiplies the current cluster with
+  __shared__ int q_rank[W][32];      // per wave: the current cluster's positions in object order (Scene::cull_rank)
+  __shared__ int q_cnt[W], q_live[W];
+  __shared__ WaveShared sh_all[W];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  WaveShared &sh = sh_all[wave];
+  const int n_tiles = s.n_cull_tiles;
+  const int n_groups = (n_tiles + 32 * W - 1) / (32 * W); // a group: 32 clusters per wave, cluster 32 W g + W i + wave is this wave's i-th
+  const float4 *ray_quads = reinterpret_cast<const float4 *>(q_ray);
+  WavePath<true> L;
+  L.init(p, sh, blockIdx.x * W + wave);
+#ifdef RT_PROFILE_PHASES
+  unsigned long long t_queue = 0, t_l1 = 0, t_l2 = 0, t_shade = 0, n_iter = 0, n_rays_q = 0, n_blocks = 0, n_pairs = 0, n_lists = 0;
+#define RT_CSTAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define RT_CSTAMP(var)
+#endif
+
+  // the B operands and the lane's own quad of the ray in `slot`
+  struct RayBlock {
+    float4 qb0, qb1, qc0, qc1, qc;
+  };
+  auto load_block = [&](int slot) {
+    const float4 *quads = ray_quads + 8 * slot;
+    const int sw = (slot >> 1) & 7;
+    RayBlock r;
+    r.qb0 = quads[half ^ sw], r.qb1 = quads[2 ^ sw], r.qc0 = quads[(3 + half) ^ sw], r.qc1 = quads[5 ^ sw], r.qc = quads[6 ^ sw];
+    return r;
+  };
+  auto load_tile = [&](const float *tiles, int tile, float4 &a0, float4 &a1) {
+    const float4 *rec = reinterpret_cast<const float4 *>(tiles + (size_t)tile * RT_TILE_WORDS);
+    a0 = rec[lane], a1 = rec[64 + lane];
+  };
+  auto load_cluster = [&](int tile, float4 &a0, float4 &a1, int &rk) {
+    load_tile(s.cull_tiles, tile, a0, a1);
+    rk = s.cull_rank[tile * 32 + col];
+  };
+
+  for (;;) {
+    // -- every lane gets a ray from its wave's node pool; the live rays are queued, compacted per wave (as rt_tile.h) ----
+    RT_CSTAMP(ts0);
+    const bool wave_live = L.deal(s, p, sh);
+    const unsigned long long live = __ballot(L.active);
+    if (lane == 0)
+      q_cnt[wave] = __popcll(live), q_live[wave] = wave_live ? 1 : 0;
+    int my_q = -1;
+    if (L.active) {
+      my_q = 64 * wave + __popcll(live & ((1ull << lane) - 1ull));
+      int self = L.origin_shape >= 0 ? s.shape_origin[4 * L.origin_shape + 1] : -1;
+      if (self >= 0)
+        self = s.cull_pos[self];
+      TileRayBf::make(L.ray, self).store(reinterpret_cast<float4 *>(q_ray), my_q);
+      q_key[my_q] = ~0ull;
+    }
+    __syncthreads();
+    int any_live = 0, cnt[W]; // uniform
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      cnt[w] = __builtin_amdgcn_readfirstlane(q_cnt[w]);
+      any_live |= __builtin_amdgcn_readfirstlane(q_live[w]);
+    }
+    if (!any_live)
+      break;
+    RT_CSTAMP(ts1);
+#ifdef RT_PROFILE_PHASES
+    t_queue += ts1 - ts0, n_iter += 1, n_rays_q += __builtin_amdgcn_readfirstlane(q_cnt[wave]);
+#endif
+
+    for (int g = 0; g < n_groups; ++g) {
+      RT_CSTAMP(tg0);
+      // -- level 1: every ray of the workgroup against the bounds of this wave's 32 clusters of the group -------------
+      // lane l ends up with the word of the ray in slot 64 w + l in mw[w] (bit i: the ray's line meets the bound of the wave's i-th
+      // cluster with the far root beyond tmin) — in registers, nothing is exchanged between the waves
+      uint32_t mw[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        mw[w] = 0u;
+      {
+        float4 a0, a1;
+        load_tile(s.cull_bounds, g * W + wave_u, a0, a1);
+#pragma unroll 1
+        for (int blk = 0; blk < 2 * W; ++blk) {
+          const int w_src = blk >> 1, r0 = 32 * (blk & 1);
+          int n_src = cnt[0];
+#pragma unroll
+          for (int w = 1; w < W; ++w)
+            n_src = w_src == w ? cnt[w] : n_src;
+          if (r0 >= n_src)
+            continue;
+          const bool valid = r0 + col < n_src;
+          const int slot = 64 * w_src + (valid ? r0 + col : 0);
+          const RayBlock rb = load_block(slot);
+          const float oo = valid ? rb.qc.x : INF_F, tmin_u = rb.qc.y;
+          f32x16 b, c;
+          tile_products_bf16(a0, a1, rb.qb0, rb.qb1, rb.qc0, rb.qc1, b, c);
+          // bit r (from the top, in the order the registers come): the line meets bound r (d > O.O) and the far root
+          // -b + sqrt(d - O.O) is beyond tmin, i.e. NOT (b + tmin > 0 and d - O.O < (b + tmin)^2); all in sign bits
+          uint32_t m = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = fmaf(b[r], b[r], -c[r]);
+            const float miss = oo - d;           // < 0: the line meets the bound
+            const float x = b[r] + tmin_u;       // < 0: the bound's centre is ahead of tmin
+            const float y = fmaf(x, x, miss);    // < 0: the far root is beyond tmin
+            const uint32_t keep = __float_as_uint(miss) & (__float_as_uint(x) | __float_as_uint(y));
+            m = (m >> 1) | (keep & 0x80000000u);
+          }
+          m >>= 16; // bit r = register r = row 8 (r / 4) + 4 half + r % 4 of the tile
+          uint32_t word = (m & 0xfu) | ((m & 0xf0u) << 4) | ((m & 0xf00u) << 8) | ((m & 0xf000u) << 12);
+          word <<= 4 * half;
+          word |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(word), 32)); // the other half of the wave holds the ray's other 16 rows
+          const bool mine = half == (blk & 1); // lanes 0-31 keep the words of rays 0-31 of the 64, lanes 32-63 of rays 32-63
+#pragma unroll
+          for (int w = 0; w < W; ++w)
+            mw[w] = (mine && w_src == w) ? word : mw[w];
+        }
+      }
+      RT_CSTAMP(tg1);
+      // -- level 2: this wave's clusters against the rays that meet their bounds --------------------------------
+      const int first = 32 * W * g + wave_u;
+      // one cluster: the workgroup's rays that meet its bound, listed and multiplied with its tile (operand words a0 | a1)
+      auto do_cluster = [&](int tb, int tile, const float4 &a0, const float4 &a1, int rk) {
+          int n_tot = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const bool meets = (mw[w] >> tb) & 1u;
+            const unsigned long long bal = __ballot(meets);
+            if (meets)
+              q_list[wave][n_tot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
+                  static_cast<uint8_t>(64 * w + lane);
+            n_tot += __popcll(bal);
+          }
+          n_tot = __builtin_amdgcn_readfirstlane(n_tot);
+#ifdef RT_PROFILE_PHASES
+          n_pairs += n_tot, n_blocks += (n_tot + 31) / 32, n_lists += 1;
+#endif
+          if (n_tot > 0 && half == 0)
+            q_rank[wave][col] = rk;
+          wave_sync();
+#pragma unroll 1
+          for (int r0 = 0; r0 < n_tot; r0 += 32) {
+            const bool valid = r0 + col < n_tot;
+            const int slot = q_list[wave][valid ? r0 + col : 0];
+            const RayBlock rb = load_block(slot);
+            const float oo = valid ? rb.qc.x : INF_F; // a lane past the list's end asks d > +inf
+            const float tmin_u = rb.qc.y, inv_len = rb.qc.z;
+            const int self = __float_as_int(rb.qc.w);
+            f32x16 b, c;
+            tile_products_bf16(a0, a1, rb.qb0, rb.qb1, rb.qc0, rb.qc1, b, c);
+            float d[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              d[r] = fmaf(b[r], b[r], -c[r]);
+            float gmax[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+              gmax[q] = fmaxf(fmaxf(d[3 * q], d[3 * q + 1]), d[3 * q + 2]);
+            const float m = fmaxf(fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]), fmaxf(fmaxf(gmax[3], gmax[4]), d[15]));
+            if (m > oo) { // this ray's line meets one of the cluster's spheres
+              unsigned long long best = ~0ull;
+              const int base = tile * 32 + 4 * half; // cluster position of this lane's row 0
+              const int self_rel = self - base;
+              auto candidate = [&](int r) {
+                if (d[r] > oo) {
+                  const int row = 8 * (r >> 2) + (r & 3); // a literal
+                  // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+                  const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
+                  const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                  const float u = u1 < tmin_u ? u2 : u1;
+                  if (u > tmin_u && self_rel != row) {
+                    // within a cluster the rows ascend with the object index (rt_scene.hip): equal t resolve as the reference's strict `<`
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(4 * half + row);
+                    best = min(best, key);
+                  }
+                }
+              };
+#pragma unroll
+              for (int q = 0; q < 5; ++q) {
+                if (gmax[q] > oo) {
+                  candidate(3 * q);
+                  candidate(3 * q + 1);
+                  candidate(3 * q + 2);
+                }
+              }
+              candidate(15);
+              if (best != ~0ull) {
+                // across clusters the key carries the sphere's position in OBJECT order
+                const unsigned rank = static_cast<unsigned>(q_rank[wave][(unsigned)best & 31u]);
+                atomicMin(&q_key[slot], (best & 0xffffffff00000000ull) | rank);
+              }
+            }
+          }
+          wave_sync(); // the list is rewritten for the next cluster
+      };
+      // The tiles come from L2 one cluster ahead, into two register sets used in turn (a copy from a "next" set makes the
+      // compiler wait for the load where it is issued)
+      float4 e0, e1, o0, o1;
+      int e_rk = 0, o_rk = 0;
+      if (first < n_tiles)
+        load_cluster(first, e0, e1, e_rk);
+#pragma unroll 1
+      for (int tb = 0; tb < 32; tb += 2) {
+        const int tile = first + W * tb; // uniform
+        if (tile >= n_tiles)
+          break;
+        const bool odd = tile + W < n_tiles;
+        if (odd)
+          load_cluster(tile + W, o0, o1, o_rk);
+        do_cluster(tb, tile, e0, e1, e_rk);
+        if (!odd)
+          break;
+        if (tb + 2 < 32 && tile + 2 * W < n_tiles)
+          load_cluster(tile + 2 * W, e0, e1, e_rk);
+        do_cluster(tb + 1, tile + W, o0, o1, o_rk);
+      }
+#ifdef RT_PROFILE_PHASES
+      RT_CSTAMP(tg2);
+      t_l1 += tg1 - tg0, t_l2 += tg2 - tg1;
+#endif
+    }
+    __syncthreads();
+    RT_CSTAMP(ts2);
+
+    // -- every lane is a ray again: finish the query, shade, produce the next ray (as rt_tile.h) -------------------
+    Hit h;
+    h.object = h.shape = -1;
+    h.t = 0.f;
+    h.point = h.normal = h.local = mk3(0.f, 0.f, 0.f);
+    TileRayBf::restore(ray_quads, max(my_q, 0), L.ray); // every lane, so that no lane's old values stay live across the scan
+    if (L.active) {
+      const unsigned long long key = q_key[my_q];
+      Best best;
+      best.t = INF_F;
+      best.object = 0x7fffffff;
+      best.shape = -1;
+      scan_spheres<true>(s.wide_lane, s.n_wide_lane, L.ray, best, L.origin_shape); // in object order: strict `<` among them
+      self_sphere_exact(s, L.origin_shape, L.ray, best);
+      if (key != ~0ull) {
+        const int2 ids = *reinterpret_cast<const int2 *>(&s.wide_recs[(int)(unsigned)(key & 0xffffffffull)].object); // {object, shape}
+        const float t = __uint_as_float((unsigned)(key >> 32));
+        if (t < best.t || (t == best.t && ids.x < best.object)) {
+          best.t = t;
+          best.object = ids.x;
+          best.shape = ids.y;
+        }
+      }
+      h = world_finish_hit<true, true, CSG>(s, L.ray, best);
+    }
+    L.shade(s, p, sh, h);
+#ifdef RT_PROFILE_PHASES
+    RT_CSTAMP(ts3);
+    t_shade += ts3 - ts2;
+#endif
+  }
+#ifdef RT_PROFILE_PHASES
+  if (lane == 0) { // per wave; counters 4-12
+    atomicAdd(p.counters + 4, t_queue), atomicAdd(p.counters + 5, t_l1), atomicAdd(p.counters + 6, t_l2), atomicAdd(p.counters + 11, t_shade);
+    atomicAdd(p.counters + 7, n_iter), atomicAdd(p.counters + 8, n_rays_q), atomicAdd(p.counters + 10, n_blocks), atomicAdd(p.counters + 12, n_pairs);
+    atomicAdd(p.counters + 13, n_lists);
+  }
+#endif
+  wave_add_tally(p.counters, 0, L.rays);
+}
+
+} // namespace rtd

@@ -76,6 +76,12 @@ struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit sha
 #define RT_TILE_BF16 1 // the tile kernel's sphere filter on bf16 MFMAs (operands split 3-way); 0: on binary32 MFMAs (rounds 2-3a)
 #endif
 constexpr int RT_TILE_WORDS = RT_TILE_BF16 ? 512 : 192;
+// From how many sphere tiles on a world's register spheres are ALSO kept as spatial clusters with bounding spheres, and the
+// tile kernel multiplies a tile only with the rays whose line meets its bound (rt_tile_cull.h)
+#ifndef RT_CULL_MIN_TILES
+#define RT_CULL_MIN_TILES 48
+#endif
+constexpr int RT_CULL_W = 4; // waves per workgroup of that kernel: cluster t belongs to wave t % RT_CULL_W
 
 struct Scene {
   // scan lists
@@ -91,6 +97,11 @@ struct Scene {
   //  binary32 build: three rows of 64 floats — lane l takes cx | cy, cz | 1, cz | k of sphere l % 32 for l < 32 | l >= 32;
   //    a place past n_wide holds 0 0 0 and k = +inf (never hit)
   const float *wide_tiles; int32_t n_wide_tiles;
+  // rt_tile_cull.h (worlds of RT_CULL_MIN_TILES tiles or more, bf16 build; else n_cull_tiles = 0): the same spheres regrouped into
+  // spatial clusters of 32 — tiles as above in cluster order; the clusters' bounding spheres as tiles of the same form, one tile
+  // per group of 32 RT_CULL_W clusters and wave: row i of tile g RT_CULL_W + w bounds cluster 32 RT_CULL_W g + RT_CULL_W i + w;
+  // cluster position -> position in wide_recs (-1: an empty place) and the inverse
+  const float *cull_tiles; const float *cull_bounds; const int32_t *cull_rank; const int32_t *cull_pos; int32_t n_cull_tiles;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling
   // every transformation of the world (shapes, CSG leaves with their ancestors folded in) is translation * axis-aligned scaling:
   // all off-diagonal entries of shape_fwd / shape_inv / shape_w2l / shape_l2w are zero.  True for every sample scene of the

@@ -2,6 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include "rt_tile.h"
+#if RT_TILE_BF16
+#include "rt_tile_cull.h"
+#endif
 
 #ifndef RT_TILE_S
 #define RT_TILE_S 8
@@ -22,3 +25,13 @@ const void *rt_tile_kernel(int waves, bool csg) {
 }
 
 int rt_tile_s() { return RT_TILE_S; }
+
+// k_render_path_tile_cull<4, CSG> (rt_tile_cull.h): worlds of RT_CULL_MIN_TILES sphere tiles or more; nullptr in the binary32 build
+const void *rt_tile_cull_kernel(bool csg) {
+#if RT_TILE_BF16
+  return csg ? reinterpret_cast<const void *>(rtd::k_render_path_tile_cull<4, true>) : reinterpret_cast<const void *>(rtd::k_render_path_tile_cull<4, false>);
+#else
+  (void)csg;
+  return nullptr;
+#endif
+}

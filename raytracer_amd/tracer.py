@@ -36,6 +36,7 @@ class RenderMode:
     object_space_spheres: bool = False           # path mode, large worlds: never use the world-space sphere form
     bvh: bool = False                            # path mode: closest sphere through a BVH instead of the linear scan
     valu_only: bool = False                      # path mode, large worlds: the sphere filter on the vector ALU, no MFMA instruction
+    scan_all_tiles: bool = False                 # path mode, worlds of many sphere tiles: every ray against every tile (no cluster bounds)
 
 
 @dataclass
@@ -186,7 +187,8 @@ class GpuImageTracer:
         cfg.n_local_rows = rows.n_local_rows
         cfg.flags = (abi.RT_FLAG_EXACT_ARITHMETIC if mode.exact else 0) | \
             (abi.RT_FLAG_OBJECT_SPACE_SPHERES if mode.object_space_spheres else 0) | \
-            (abi.RT_FLAG_ACCEL_BVH if mode.bvh else 0) | (abi.RT_FLAG_VALU_ONLY if mode.valu_only else 0)
+            (abi.RT_FLAG_ACCEL_BVH if mode.bvh else 0) | (abi.RT_FLAG_VALU_ONLY if mode.valu_only else 0) | \
+            (abi.RT_FLAG_SCAN_ALL_TILES if mode.scan_all_tiles else 0)
         return cfg
 
     def fire_all_rays(self, world: DeviceWorld, mode: RenderMode, rows: RowBands | None = None, out=None,

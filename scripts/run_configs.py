@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--synth", nargs=4, type=int, action="append", default=[], metavar=("N", "W", "H", "AA"))
     ap.add_argument("--skip-samples", action="store_true")
     ap.add_argument("--bvh", action="store_true", help="synthetic scenes: RT_FLAG_ACCEL_BVH")
+    ap.add_argument("--scan-all", action="store_true", help="synthetic scenes: RT_FLAG_SCAN_ALL_TILES (no cluster bounds)")
     args = ap.parse_args()
     if not args.skip_samples:
         onoff = FlatScene.from_json(os.path.join(GOLDEN, "demo_onoff.scene.json"))
@@ -61,7 +62,7 @@ def main():
         run("C4 csg_example", csg, RenderMode("path"), 1920, 1080, 4)
     for n, w, h, aa in args.synth:
         scene, _ = synthetic_scene(n)
-        run(f"synthetic {n} spheres" + (" (BVH)" if args.bvh else ""), scene, RenderMode("path", bvh=args.bvh), w, h, aa, reps=1)
+        run(f"synthetic {n} spheres" + (" (BVH)" if args.bvh else ""), scene, RenderMode("path", bvh=args.bvh, scan_all_tiles=args.scan_all), w, h, aa, reps=1)
 
 
 if __name__ == "__main__":

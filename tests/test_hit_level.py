@@ -107,7 +107,7 @@ def test_fast_scans_pick_the_reference_winner(n):
                        ("bvh-unfused", RenderMode("path", bvh=True, exact=True, **kw))):
         renders[name] = ids_of(tr.fire_all_rays(world, mode))
         if name == "wide-world-space":
-            assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+            assert tr.last_stats.kernel.decode().startswith("k_render_path_tile")
     world.close()
     want = ids_of(O.render(scene, O.make_cfg(W, H, "path", spp_edge=1, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))[0])
     ref1, ref2 = renders["unfused"]

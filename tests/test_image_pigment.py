@@ -124,7 +124,7 @@ def test_gpu_deterministic_modes_within_the_uv_budget(images, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,kernel_prefix", [("image_pigment", "k_render_path_wave<"), ("image_pigment_many", "k_render_path_tile<")])
+@pytest.mark.parametrize("name,kernel_prefix", [("image_pigment", "k_render_path_wave<"), ("image_pigment_many", "k_render_path_tile")])
 def test_gpu_path_statistical_vs_reference_36spp(images, meta, name, kernel_prefix):
     """RMSE bound against the reference's 36-spp serial-PCG render (as tests/test_gpu_parity.py::test_path_statistical_vs_reference_high_spp):
     two independent unbiased 36-spp estimates differ with mean square 2 s^2 / 36; s^2 comes from a second device render with another

@@ -50,7 +50,7 @@ def test_gpu_flat_equals_reference(ref_images, big_scenes, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,w,h,kernel", [(512, 128, 72, "k_render_path_tile<"), (4096, 48, 27, "k_render_path_tile<")])
+@pytest.mark.parametrize("n,w,h,kernel", [(512, 128, 72, "k_render_path_tile"), (4096, 48, 27, "k_render_path_tile")])
 def test_gpu_wide_kernel_converges_to_reference_render(ref_images, big_scenes, n, w, h, kernel):
     from raytracer_amd.tracer import DeviceWorld, GpuImageTracer, RenderMode
     scene = big_scenes[n]
@@ -96,7 +96,7 @@ def test_gpu_rmse_vs_reference_36spp_n512(hispp, big_scenes):
     world = DeviceWorld(scene)
     tr = GpuImageTracer(64, 36, scene.camera, 6)
     a = tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=54)).astype(np.float64)
-    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile")
     b = tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=1234)).astype(np.float64)
     world.close()
     mse_dd, mse_dr = float(np.mean((a - b) ** 2)), float(np.mean((a - ref) ** 2))
@@ -122,7 +122,7 @@ def test_gpu_rmse_vs_reference_36_renders_n4096(hispp, big_scenes):
     imgs = []
     for seed in range(54, 90):
         imgs.append(tr.fire_all_rays(world, RenderMode("path", n_rays=10, roulette=3, max_depth=5, seq_number=seed)).astype(np.float64))
-        assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+        assert tr.last_stats.kernel.decode().startswith("k_render_path_tile")
     world.close()
     stack = np.stack(imgs)
     dev_mean, dev_std = stack.mean(0), stack.std(0, ddof=1)
@@ -198,7 +198,7 @@ def test_furnace_identity_at_full_sphere_counts(n):
                        ("bvh", RenderMode("path", bvh=True, **kw))):
         img = tr.fire_all_rays(world, mode)
         if name == "tile":
-            assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+            assert tr.last_stats.kernel.decode().startswith("k_render_path_tile")
         full = 96 * 54 * 4 * 31  # every ray hits something: full binary trees of depth 4
         assert full * (1 - 1e-4) <= int(tr.last_stats.rays) <= full
         print(f"n={n} {name}: {full - int(tr.last_stats.rays)} rays short of {full}, {int((img != np.float32(1.9375)).any(axis=2).sum())} pixels off, min {img.min()}")
@@ -219,7 +219,7 @@ def test_valu_only_flag_selects_the_kernel_without_matrix_instructions(big_scene
     tr = GpuImageTracer(64, 36, scene.camera, 1)
     kw = dict(n_rays=3, roulette=2, max_depth=3, seq_number=21)
     tile = tr.fire_all_rays(world, RenderMode("path", **kw))
-    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile")
     valu = tr.fire_all_rays(world, RenderMode("path", valu_only=True, **kw))
     assert tr.last_stats.kernel.decode().startswith("k_render_path_wide<ISO")
     world.close()
