@@ -123,6 +123,28 @@ def load_profile(name):
     return j
 
 
+def valu_issue_block(profile, rays, kernel_ms):
+    """The vector ALU's issue slots as a bound: VALU wave-instructions per ray by class (the profile's SQ_INSTS_VALU* counters) x the
+    measured issue cost of each class, against the SIMD-cycles per ray of this very launch.  None without the counters."""
+    c = profile["counters"]
+    if "SQ_INSTS_VALU_FMA_F32" not in c:
+        return None
+    n = float(profile["rays_per_launch"]) * float(profile.get("launches", 1))
+    fast = (c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / n
+    trans = c["SQ_INSTS_VALU_TRANS_F32"] / n
+    mfma = (c.get("SQ_INSTS_VALU_MFMA_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_F32", 0.0)) / n  # counted in SQ_INSTS_VALU, issued to the matrix pipe
+    total = c["SQ_INSTS_VALU"] / n - mfma
+    model = fast * VALU_CYCLES_FAST + trans * VALU_CYCLES_TRANS + (total - fast - trans) * VALU_CYCLES_OTHER
+    clk = profile.get("derived", {}).get("clock_ghz", 2.3)
+    measured = kernel_ms * 1e-3 * clk * 1e9 * SIMDS / rays
+    return {"valu_wave_instr_per_ray": total, "fp32_add_mul_fma_per_ray": fast, "transcendental_per_ray": trans,
+            "modelled_valu_cycles_per_ray": model, "simd_cycles_per_ray_this_launch": measured, "clock_ghz": clk,
+            "frac": model / measured, "source": profile["_source"], "saturated": model / measured >= 0.9,
+            "note": "modelled / measured issue cycles: near 1 = the vector ALU issues all the time.  'other' is priced at 4.2 cycles although the "
+                    "plain moves, integer adds and logic ops in it issue at 2.3, so the model is an upper estimate and can exceed 1 by that "
+                    "margin (C3 / C4: 1.07-1.08)"}
+
+
 def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
     """One roofline block.  Every number can be recomputed from this line and the profile it names:
        frac_executed    = rays x flops_per_ray (what the kernel issues, FMA = 2) / kernel_ms / peak            (<= 1 by construction)
@@ -144,6 +166,50 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
     executed, algorithmic = flops_per_ray(census, kernel)
     ach = rays * executed / (kernel_ms * 1e-3) / 1e12
     alg = rays * algorithmic / (kernel_ms * 1e-3) / 1e12
+    if "tile_cull" in kernel:
+        # The cluster-culled tile kernel (rt_tile_cull.h) multiplies a sphere tile only with the rays that meet its bound: the flops it
+        # executes are data dependent, so they are taken from the committed counter profile of this very workload (None without one),
+        # never from a formula.  It is bound by the vector ALU's ISSUE slots (valu_issue), not by flops and not by the matrix pipe:
+        #   achieved / frac  = fp32 flops the vector ALU executed (2 x FMA + MUL + ADD wave-instructions x the mean number of active lanes)
+        #                      against the fp32 vector peak
+        #   mfma             = bf16 matrix flops (32768 per v_mfma_f32_32x32x16_bf16) against the dense bf16 peak
+        #   frac_algorithmic = the reference's arithmetic as written (52 fp32 flops per sphere test, ALL spheres) against the fp32 peak
+        out = {"bound": "valu", "peak_kind": "fp32 vector ALU, 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz; the kernel is bound by the vector ALU's issue slots (valu_issue), "
+                                              "its bf16 matrix work is in `mfma`",
+               "achieved": None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "frac_executed": None,
+               "frac_algorithmic": alg / FP32_VALU_PEAK_TFLOPS, "algorithmic_peak_kind": "fp32 vector peak, 157.3 TFLOP/s",
+               "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": alg,
+               "traffic": None, "traffic_source": None, "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms,
+               "note": "this kernel skips the tile products whose outcome is known (a ray's line misses the cluster's bounding sphere): 19 of 128 per 32 rays are "
+                       "left on the headline world, the frame is bit-identical (share0_sha256), the time per ray halves.  What is left is list building, "
+                       "LDS gathers and candidate handling - vector-ALU ISSUE work, few flops: `frac` (fp32 flops executed / fp32 peak) is small by nature, "
+                       "`valu_issue.frac` says how full the issue slots are, `mfma.frac` how busy the matrix pipe is.  The kernel that does ALL the tile "
+                       "products and sits on the matrix-pipe roofline is the sub-record N4096-share-scan-all (RT_FLAG_SCAN_ALL_TILES)."}
+        if profile is not None and "cull" in profile.get("kernel", ""):
+            c, launches = profile["counters"], float(profile.get("launches", 1))
+            n = float(profile["rays_per_launch"]) * launches
+            secs = kernel_ms * 1e-3
+            if "SQ_INSTS_VALU_FMA_F32" in c:
+                lanes = profile.get("derived", {}).get("active_lanes_per_valu_instr", 64.0)
+                flops = (2.0 * c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / n * lanes
+                out["achieved"] = rays * flops / secs / 1e12
+                out["frac"] = out["frac_executed"] = out["achieved"] / FP32_VALU_PEAK_TFLOPS
+                out["valu_fp32_flops_per_ray"] = flops
+                out["mean_active_lanes"] = lanes
+            if "SQ_INSTS_VALU_MFMA_BF16" in c:
+                per_ray = c["SQ_INSTS_VALU_MFMA_BF16"] / n
+                tf = rays * per_ray * 32768.0 / secs / 1e12
+                n_tiles = -(-max(census["spheres"] - 1, 0) // 32)
+                out["mfma"] = {"achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "frac": tf / BF16_MFMA_PEAK_TFLOPS, "mfma_instr_per_ray": per_ray,
+                               "tile_products_per_32_rays": per_ray * 32.0 / 4.0, "scan_all_tile_products_per_32_rays": float(n_tiles)}
+            vi = valu_issue_block(profile, rays, kernel_ms)
+            if vi:
+                out["valu_issue"] = vi
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
+                out["traffic_source"] = profile["_source"]
+            out["source"] = profile["_source"]
+        return out
     if "BF16x3" in kernel:
         # The dominant unit is the bf16 matrix pipe: `achieved` / `frac` / `frac_executed` count ITS flops against ITS peak.  The fp32
         # work that stays on the vector ALU (d = b^2 - c per test, the per-lane sphere, planes, hit record, exact record, shading) is
@@ -178,21 +244,9 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             out["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / launches
             out["traffic_source"] = profile["_source"]
-        if "SQ_INSTS_VALU_FMA_F32" in c:
-            n = float(profile["rays_per_launch"]) * launches
-            fast = (c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]) / n
-            trans = c["SQ_INSTS_VALU_TRANS_F32"] / n
-            total = c["SQ_INSTS_VALU"] / n
-            model = fast * VALU_CYCLES_FAST + trans * VALU_CYCLES_TRANS + (total - fast - trans) * VALU_CYCLES_OTHER
-            clk = profile.get("derived", {}).get("clock_ghz", 2.3)
-            measured = kernel_ms * 1e-3 * clk * 1e9 * SIMDS / rays
-            out["valu_issue"] = {"valu_wave_instr_per_ray": total, "fp32_add_mul_fma_per_ray": fast, "transcendental_per_ray": trans,
-                                 "modelled_valu_cycles_per_ray": model, "simd_cycles_per_ray_this_launch": measured, "clock_ghz": clk,
-                                 "frac": model / measured, "source": profile["_source"],
-                                 "saturated": model / measured >= 0.9,
-                                 "note": "modelled / measured issue cycles: near 1 = the vector ALU issues all the time.  'other' is priced at 4.2 cycles although the "
-                                         "plain moves, integer adds and logic ops in it issue at 2.3, so the model is an upper estimate and can exceed 1 by that "
-                                         "margin (C3 / C4: 1.07-1.08)"}
+        vi = valu_issue_block(profile, rays, kernel_ms)
+        if vi:
+            out["valu_issue"] = vi
     return out
 
 
@@ -287,9 +341,13 @@ def measure_configs(device, log):
     # brute-force ray x sphere filter turned out to be one): the vector-ALU filter kernel.
     run("N512-valu-only", "the same frame with RT_FLAG_VALU_ONLY: the sphere filter on the vector ALU, no matrix-core instruction",
         small, RenderMode("path", valu_only=True), 1920, 1080, 4, reps=1)
+    big = synthetic_scene(4096)[0]
+    # The headline's own share 0 with every ray against every tile (RT_FLAG_SCAN_ALL_TILES: round 3a's kernel, the matrix-pipe roofline)
+    run("N4096-share-scan-all", "the headline's share 0 (1/16 of the 4096-sphere 1920x1080 AA=4 frame) with RT_FLAG_SCAN_ALL_TILES: the bf16 matrix filter on "
+        "every tile, no cluster bounds", big, RenderMode("path", scan_all_tiles=True), 1920, 1080, 4, rows=RowBands.cyclic(1080, 0, 16, 1), reps=1,
+        profile="n4096_share_scan_all")
     # The headline's own share 0 with the filter in binary32 on the vector ALU: the figure to hold against `value` if the bf16-split
     # matrix filter is to be discounted (it loses no accuracy — DESIGN.md 4.4 — but it is not binary32 arithmetic instruction by instruction).
-    big = synthetic_scene(4096)[0]
     run("N4096-share-valu-only", "the headline's share 0 (1/16 of the 4096-sphere 1920x1080 AA=4 frame) with RT_FLAG_VALU_ONLY: binary32 filter on the vector ALU, no matrix-core instruction",
         big, RenderMode("path", valu_only=True), 1920, 1080, 4, rows=RowBands.cyclic(1080, 0, 16, 1), reps=1)
     return recs
@@ -317,6 +375,8 @@ def main():
     ap.add_argument("--bvh", action="store_true",
                     help="RT_FLAG_ACCEL_BVH: not the reference's algorithmic work, so the line carries no roofline fraction")
     ap.add_argument("--valu-only", action="store_true", help="RT_FLAG_VALU_ONLY: the large-world sphere filter on the vector ALU (no MFMA instruction)")
+    ap.add_argument("--scan-all-tiles", dest="scan_all_tiles", action="store_true",
+                    help="RT_FLAG_SCAN_ALL_TILES: every ray against every sphere tile (no cluster bounds)")
     ap.add_argument("--save-pfm", default=None, help="write the frame buffer here at the end (rank 0; the rows of shares not rendered are zero)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices, gather staged through the host)")
@@ -356,7 +416,8 @@ def main():
         scene, text = synthetic_scene(args.spheres)
     world = DeviceWorld(scene, dev_index)
     tracer = GpuImageTracer(args.width, args.height, scene.camera, args.aa)
-    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh, valu_only=args.valu_only)
+    mode = RenderMode("path", n_rays=args.n_rays, roulette=args.roulette, max_depth=args.max_depth, seq_number=54, bvh=args.bvh, valu_only=args.valu_only,
+                      scan_all_tiles=args.scan_all_tiles)
     max_rows = -(-args.height // args.shares)
     local = torch.empty((max_rows, args.width, 3), dtype=torch.float32, device=device)
     full = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
@@ -452,7 +513,7 @@ def main():
             "config": {"workload": (f"samples/{args.scene} (reference sample scene)" if args.scene else
                                     f"synthetic {args.spheres}-random-sphere + floor + sky scene") + f", --mode path, "
                                    f"{args.width}x{args.height}, AA={args.aa}, n_rays={args.n_rays}, roulette={args.roulette}, "
-                                   f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else "") +
+                                   f"max-depth={args.max_depth}, seq-number=54" + (", BVH mode (RT_FLAG_ACCEL_BVH)" if args.bvh else "") + (", RT_FLAG_SCAN_ALL_TILES" if args.scan_all_tiles else "") +
                                    (f"; one step = one row-cyclic share of 1/{args.shares} of the frame per GPU (rows k, k + {args.shares}, ...), "
                                     f"consecutive steps render consecutive shares" if args.shares > 1 else "; one step = the whole frame"),
                        "objects": scene.count("n_objects"), "top_level": {k: census[k] for k in ("spheres", "planes", "csg")},
@@ -464,7 +525,8 @@ def main():
             "gather_ms_per_step": {"rank0_including_wait_for_slowest_rank": gather_ms, "min_over_ranks": float(g[0])},
             # dominant kernel on rank 0's shares: ITS rays / ITS duration (k_resolve rides in the same interval, < 0.1 %)
             "roofline": roofline_block(census, kernel_name, rays_per_step_rank0, kernel_ms,
-                                       load_profile("n4096_share") if (default_workload and world_size == 1) else None, bvh=args.bvh),
+                                       load_profile("n4096_share_scan_all" if args.scan_all_tiles else "n4096_share") if (default_workload and world_size == 1) else None,
+                                       bvh=args.bvh),
             # share 0 as rank 0 rendered it in the first pass: bit-identical for any number of ranks and any kernel shape
             "share0_sha256": share0_sha,
         }

@@ -542,11 +542,12 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       const size_t k = t * 32 + i;
       pack_tile_row(&wide_tiles[t * rtd::RT_TILE_WORDS], i, k < wide_recs.size() ? &wide_iso[4 * k] : never_hit);
     }
-  // The same spheres once more as spatial CLUSTERS of 32 with a bounding sphere each (rt_tile_cull.h): a k-d split of the centres
-  // at multiples of 32 along the widest axis, so that every cluster but the last is full.  cull_rank maps a cluster position back
-  // to the position in wide_recs (object order: what a hit's key carries, so that equal distances resolve as the reference's
-  // strict `<` does), cull_pos is the inverse (the sphere a ray leaves is excluded by position).
+  // The same spheres once more as spatial CLUSTERS of CS = 32 RT_CULL_C with a bounding sphere each (rt_tile_cull.h): a k-d split of
+  // the centres at multiples of CS along the widest axis, so that every cluster but the last is full.  cull_rank maps a cluster
+  // position back to the position in wide_recs (object order: what a hit's key carries, so that equal distances resolve as the
+  // reference's strict `<` does), cull_pos is the inverse (the sphere a ray leaves is excluded by position).
   if (n_wide_tiles >= RT_CULL_MIN_TILES) {
+    constexpr size_t CC = rtd::RT_CULL_C, CS = 32 * CC;
     const size_t n = wide_recs.size();
     std::vector<int32_t> order(n);
     for (size_t k = 0; k < n; ++k)
@@ -555,7 +556,7 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
     while (!todo.empty()) {
       const auto [b, e] = todo.back();
       todo.pop_back();
-      if (e - b <= 32)
+      if (e - b <= CS)
         continue;
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
       for (size_t k = b; k < e; ++k)
@@ -565,27 +566,27 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       for (int a = 1; a < 3; ++a)
         if (hi[a] - lo[a] > hi[axis] - lo[axis])
           axis = a;
-      const size_t tiles = (e - b + 31) / 32, mid = b + 32 * ((tiles + 1) / 2);
+      const size_t parts = (e - b + CS - 1) / CS, mid = b + CS * ((parts + 1) / 2);
       std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](int32_t x, int32_t y) {
         const float fx = wide_iso[4 * x + axis], fy = wide_iso[4 * y + axis];
         return fx < fy || (fx == fy && x < y);
       });
       todo.push_back({b, mid}), todo.push_back({mid, e});
     }
-    for (size_t b = 0; b < n; b += 32) // within a cluster in object order: equal distances resolve by row (rt_tile_cull.h)
-      std::sort(order.begin() + b, order.begin() + std::min(b + 32, n));
+    for (size_t b = 0; b < n; b += CS) // within a cluster in object order: equal distances resolve by row (rt_tile_cull.h)
+      std::sort(order.begin() + b, order.begin() + std::min(b + CS, n));
     cull_rank.assign(n_wide_tiles * 32, -1);
     cull_pos.assign(n, -1);
     cull_tiles.resize(n_wide_tiles * rtd::RT_TILE_WORDS);
     constexpr size_t CW = rtd::RT_CULL_W;
-    const size_t n_groups = (n_wide_tiles + 32 * CW - 1) / (32 * CW) * CW; // bound tiles: one per group of 32 CW clusters and wave
-    cull_bounds.resize(n_groups * rtd::RT_TILE_WORDS);
-    for (size_t g = 0; g < n_groups; ++g)
+    const size_t n_clusters = (n_wide_tiles + CC - 1) / CC;
+    const size_t n_bound_tiles = (n_clusters + 32 * CW - 1) / (32 * CW) * CW; // one per group of 32 CW clusters and wave
+    cull_bounds.resize(n_bound_tiles * rtd::RT_TILE_WORDS);
+    for (size_t g = 0; g < n_bound_tiles; ++g)
       for (size_t i = 0; i < 32; ++i)
         pack_tile_row(&cull_bounds[g * rtd::RT_TILE_WORDS], i, never_hit);
-    for (size_t t = 0; t < n_wide_tiles; ++t) {
-      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      auto radius_of = [&](size_t k) { return std::fabs(static_cast<double>(d->shape_fwd[12 * static_cast<size_t>(wide_recs[k].shape)])); };
+    auto radius_of = [&](size_t k) { return std::fabs(static_cast<double>(d->shape_fwd[12 * static_cast<size_t>(wide_recs[k].shape)])); };
+    for (size_t t = 0; t < n_wide_tiles; ++t)
       for (size_t i = 0; i < 32; ++i) {
         const size_t pos = t * 32 + i;
         if (pos >= n) {
@@ -595,23 +596,58 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
         const size_t k = static_cast<size_t>(order[pos]);
         cull_rank[pos] = static_cast<int32_t>(k), cull_pos[k] = static_cast<int32_t>(pos);
         pack_tile_row(&cull_tiles[t * rtd::RT_TILE_WORDS], i, &wide_iso[4 * k]);
+      }
+    for (size_t j = 0; j < n_clusters; ++j) {
+      const size_t begin = j * CS, end = std::min(begin + CS, n);
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (size_t pos = begin; pos < end; ++pos) {
+        const size_t k = static_cast<size_t>(order[pos]);
         for (int a = 0; a < 3; ++a)
           lo[a] = std::min(lo[a], wide_iso[4 * k + a] - radius_of(k)), hi[a] = std::max(hi[a], wide_iso[4 * k + a] + radius_of(k));
       }
-      // bounding sphere about the (rounded) middle of the cluster's box; its radius^2 is inflated by more than the filter's
-      // rounding can move either of the level-1 decisions (world_filter_ok: that error is below 0.05 r_min^2 wherever this kernel runs)
-      const float centre[3] = {static_cast<float>(0.5 * (lo[0] + hi[0])), static_cast<float>(0.5 * (lo[1] + hi[1])), static_cast<float>(0.5 * (lo[2] + hi[2]))};
+      // Bounding sphere: from the middle of the cluster's box the centre walks towards the farthest sphere surface with steps
+      // 1 / (k + 1) (Badoiu-Clarkson: converges to the smallest enclosing ball), the best (rounded) centre seen is kept.  Its
+      // radius^2 is inflated by more than the filter's rounding can move either of the level-1 decisions (world_filter_ok: that
+      // error is below 0.05 r_min^2 wherever this kernel runs).
+      auto reach_from = [&](const double c[3], size_t *farthest) {
+        double reach = 0.0;
+        for (size_t pos = begin; pos < end; ++pos) {
+          const size_t k = static_cast<size_t>(order[pos]);
+          const double dx = wide_iso[4 * k] - c[0], dy = wide_iso[4 * k + 1] - c[1], dz = wide_iso[4 * k + 2] - c[2];
+          const double r = std::sqrt(dx * dx + dy * dy + dz * dz) + radius_of(k);
+          if (r > reach)
+            reach = r, *farthest = k;
+        }
+        return reach;
+      };
+      double walk[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+      float centre[3] = {static_cast<float>(walk[0]), static_cast<float>(walk[1]), static_cast<float>(walk[2])};
+      size_t far_k = 0;
       double reach = 0.0;
-      for (size_t i = 0; i < 32 && t * 32 + i < n; ++i) {
-        const size_t k = static_cast<size_t>(order[t * 32 + i]);
-        const double dx = wide_iso[4 * k] - double(centre[0]), dy = wide_iso[4 * k + 1] - double(centre[1]), dz = wide_iso[4 * k + 2] - double(centre[2]);
-        reach = std::max(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + radius_of(k));
+      {
+        const double c0[3] = {centre[0], centre[1], centre[2]};
+        reach = reach_from(c0, &far_k);
+      }
+      for (int it = 1; it <= 200; ++it) {
+        reach_from(walk, &far_k);
+        // the farthest surface point of sphere far_k seen from the walking centre
+        double dir[3] = {wide_iso[4 * far_k] - walk[0], wide_iso[4 * far_k + 1] - walk[1], wide_iso[4 * far_k + 2] - walk[2]};
+        const double len = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        const double scale = len > 0.0 ? (len + radius_of(far_k)) / len : 0.0;
+        for (int a = 0; a < 3; ++a)
+          walk[a] += dir[a] * scale / (it + 1);
+        const float cand[3] = {static_cast<float>(walk[0]), static_cast<float>(walk[1]), static_cast<float>(walk[2])};
+        const double cd[3] = {cand[0], cand[1], cand[2]};
+        size_t unused = 0;
+        const double r = reach_from(cd, &unused);
+        if (r < reach)
+          reach = r, centre[0] = cand[0], centre[1] = cand[1], centre[2] = cand[2];
       }
       const double r2 = reach * reach * (1.0 + 1.0 / 1024.0) + 0.5 * wide_rmin2;
       const double cc = double(centre[0]) * centre[0] + double(centre[1]) * centre[1] + double(centre[2]) * centre[2];
       const float v[4] = {centre[0], centre[1], centre[2], static_cast<float>(cc - r2)};
-      // cluster t = 32 CW g + CW i + w is row i of bound tile g CW + w: a wave's 32 clusters of a group are spread over the group's space
-      pack_tile_row(&cull_bounds[(t / (32 * CW) * CW + t % CW) * rtd::RT_TILE_WORDS], t % (32 * CW) / CW, v);
+      // cluster j = 32 CW g + CW i + w is row i of bound tile g CW + w: a wave's 32 clusters of a group are spread over the group's space
+      pack_tile_row(&cull_bounds[(j / (32 * CW) * CW + j % CW) * rtd::RT_TILE_WORDS], j % (32 * CW) / CW, v);
     }
   }
 #else

@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   WaveShared &sh = sh_all[wave];
   const int n_tiles = s.n_cull_tiles;
-  const int n_groups = (n_tiles + 32 * W - 1) / (32 * W); // a group: 32 clusters per wave, cluster 32 W g + W i + wave is this wave's i-th
+  constexpr int C = RT_CULL_C;                                  // tiles per cluster
+  const int n_clusters = (n_tiles + C - 1) / C;
+  const int n_groups = (n_clusters + 32 * W - 1) / (32 * W); // a group: 32 clusters per wave, cluster 32 W g + W i + wave is this wave's i-th
   const float4 *ray_quads = reinterpret_cast<const float4 *>(q_ray);
   WavePath<true> L;
   L.init(p, sh, blockIdx.x * W + wave);
@@ -149,15 +151,15 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
           // -b + sqrt(d - O.O) is beyond tmin, i.e. NOT (b + tmin > 0 and d - O.O < (b + tmin)^2); all in sign bits
           uint32_t m = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 15; r >= 0; --r) {
             const float d = fmaf(b[r], b[r], -c[r]);
             const float miss = oo - d;           // < 0: the line meets the bound
             const float x = b[r] + tmin_u;       // < 0: the bound's centre is ahead of tmin
             const float y = fmaf(x, x, miss);    // < 0: the far root is beyond tmin
             const uint32_t keep = __float_as_uint(miss) & (__float_as_uint(x) | __float_as_uint(y));
-            m = (m >> 1) | (keep & 0x80000000u);
+            m = __builtin_amdgcn_alignbit(m, keep, 31); // m << 1 | sign of keep
           }
-          m >>= 16; // bit r = register r = row 8 (r / 4) + 4 half + r % 4 of the tile
+          // bit r = register r = row 8 (r / 4) + 4 half + r % 4 of the tile
           uint32_t word = (m & 0xfu) | ((m & 0xf0u) << 4) | ((m & 0xf00u) << 8) | ((m & 0xf000u) << 12);
           word <<= 4 * half;
           word |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(word), 32)); // the other half of the wave holds the ray's other 16 rows
@@ -169,101 +171,115 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
       }
       RT_CSTAMP(tg1);
       // -- level 2: this wave's clusters against the rays that meet their bounds --------------------------------
-      const int first = 32 * W * g + wave_u;
-      // one cluster: the workgroup's rays that meet its bound, listed and multiplied with its tile (operand words a0 | a1)
-      auto do_cluster = [&](int tb, int tile, const float4 &a0, const float4 &a1, int rk) {
-          int n_tot = 0;
+      const int first = 32 * W * g + wave_u; // this wave's first cluster of the group
+      int n_tot = 0;                         // rays listed for the cluster at hand
+      // the rays of the workgroup that meet the bound of the wave's i-th cluster, listed in q_list[wave]
+      auto list_rays = [&](int tb) {
+        wave_sync(); // the list may still be read
+        n_tot = 0;
 #pragma unroll
-          for (int w = 0; w < W; ++w) {
-            const bool meets = (mw[w] >> tb) & 1u;
-            const unsigned long long bal = __ballot(meets);
-            if (meets)
-              q_list[wave][n_tot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
-                  static_cast<uint8_t>(64 * w + lane);
-            n_tot += __popcll(bal);
-          }
-          n_tot = __builtin_amdgcn_readfirstlane(n_tot);
+        for (int w = 0; w < W; ++w) {
+          const bool meets = (mw[w] >> tb) & 1u;
+          const unsigned long long bal = __ballot(meets);
+          if (meets)
+            q_list[wave][n_tot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
+                static_cast<uint8_t>(64 * w + lane);
+          n_tot += __popcll(bal);
+        }
+        n_tot = __builtin_amdgcn_readfirstlane(n_tot);
 #ifdef RT_PROFILE_PHASES
-          n_pairs += n_tot, n_blocks += (n_tot + 31) / 32, n_lists += 1;
+        n_pairs += n_tot, n_blocks += (n_tot + 31) / 32, n_lists += 1;
 #endif
-          if (n_tot > 0 && half == 0)
-            q_rank[wave][col] = rk;
-          wave_sync();
+      };
+      // one tile (operand words a0 | a1, rk: its rows' positions in object order) against the listed rays
+      auto do_tile = [&](int tile, const float4 &a0, const float4 &a1, int rk) {
+        if (half == 0)
+          q_rank[wave][col] = rk;
+        wave_sync();
 #pragma unroll 1
-          for (int r0 = 0; r0 < n_tot; r0 += 32) {
-            const bool valid = r0 + col < n_tot;
-            const int slot = q_list[wave][valid ? r0 + col : 0];
-            const RayBlock rb = load_block(slot);
-            const float oo = valid ? rb.qc.x : INF_F; // a lane past the list's end asks d > +inf
-            const float tmin_u = rb.qc.y, inv_len = rb.qc.z;
-            const int self = __float_as_int(rb.qc.w);
-            f32x16 b, c;
-            tile_products_bf16(a0, a1, rb.qb0, rb.qb1, rb.qc0, rb.qc1, b, c);
-            float d[16];
+        for (int r0 = 0; r0 < n_tot; r0 += 32) {
+          const bool valid = r0 + col < n_tot;
+          const int slot = q_list[wave][valid ? r0 + col : 0];
+          const RayBlock rb = load_block(slot);
+          const float oo = valid ? rb.qc.x : INF_F; // a lane past the list's end asks d > +inf
+          const float tmin_u = rb.qc.y, inv_len = rb.qc.z;
+          const int self = __float_as_int(rb.qc.w);
+          f32x16 b, c;
+          tile_products_bf16(a0, a1, rb.qb0, rb.qb1, rb.qc0, rb.qc1, b, c);
+          float d[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              d[r] = fmaf(b[r], b[r], -c[r]);
-            float gmax[5];
+          for (int r = 0; r < 16; ++r)
+            d[r] = fmaf(b[r], b[r], -c[r]);
+          float gmax[5];
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
-              gmax[q] = fmaxf(fmaxf(d[3 * q], d[3 * q + 1]), d[3 * q + 2]);
-            const float m = fmaxf(fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]), fmaxf(fmaxf(gmax[3], gmax[4]), d[15]));
-            if (m > oo) { // this ray's line meets one of the cluster's spheres
-              unsigned long long best = ~0ull;
-              const int base = tile * 32 + 4 * half; // cluster position of this lane's row 0
-              const int self_rel = self - base;
-              auto candidate = [&](int r) {
-                if (d[r] > oo) {
-                  const int row = 8 * (r >> 2) + (r & 3); // a literal
-                  // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
-                  const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
-                  const float u1 = -b[r] - sq, u2 = -b[r] + sq;
-                  const float u = u1 < tmin_u ? u2 : u1;
-                  if (u > tmin_u && self_rel != row) {
-                    // within a cluster the rows ascend with the object index (rt_scene.hip): equal t resolve as the reference's strict `<`
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(4 * half + row);
-                    best = min(best, key);
-                  }
-                }
-              };
-#pragma unroll
-              for (int q = 0; q < 5; ++q) {
-                if (gmax[q] > oo) {
-                  candidate(3 * q);
-                  candidate(3 * q + 1);
-                  candidate(3 * q + 2);
+          for (int q = 0; q < 5; ++q)
+            gmax[q] = fmaxf(fmaxf(d[3 * q], d[3 * q + 1]), d[3 * q + 2]);
+          const float m = fmaxf(fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]), fmaxf(fmaxf(gmax[3], gmax[4]), d[15]));
+          if (m > oo) { // this ray's line meets one of the cluster's spheres
+            unsigned long long best = ~0ull;
+            const int base = tile * 32 + 4 * half; // cluster position of this lane's row 0
+            const int self_rel = self - base;
+            auto candidate = [&](int r) {
+              if (d[r] > oo) {
+                const int row = 8 * (r >> 2) + (r & 3); // a literal
+                // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
+                const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
+                const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                const float u = u1 < tmin_u ? u2 : u1;
+                if (u > tmin_u && self_rel != row) {
+                  // within a cluster the rows ascend with the object index (rt_scene.hip): equal t resolve as the reference's strict `<`
+                  const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(4 * half + row);
+                  best = min(best, key);
                 }
               }
-              candidate(15);
-              if (best != ~0ull) {
-                // across clusters the key carries the sphere's position in OBJECT order
-                const unsigned rank = static_cast<unsigned>(q_rank[wave][(unsigned)best & 31u]);
-                atomicMin(&q_key[slot], (best & 0xffffffff00000000ull) | rank);
+            };
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+              if (gmax[q] > oo) {
+                candidate(3 * q);
+                candidate(3 * q + 1);
+                candidate(3 * q + 2);
               }
             }
+            candidate(15);
+            if (best != ~0ull) {
+              // across clusters the key carries the sphere's position in OBJECT order
+              const unsigned rank = static_cast<unsigned>(q_rank[wave][(unsigned)best & 31u]);
+              atomicMin(&q_key[slot], (best & 0xffffffff00000000ull) | rank);
+            }
           }
-          wave_sync(); // the list is rewritten for the next cluster
+        }
       };
-      // The tiles come from L2 one cluster ahead, into two register sets used in turn (a copy from a "next" set makes the
-      // compiler wait for the load where it is issued)
+      // This wave's tiles of the group in sequence (cluster after cluster, C tiles each); step q: cluster first + W (q / C), its
+      // tile q % C.  The tiles come from L2 one step ahead, into two register sets used in turn (copying from a "next" set
+      // makes the compiler wait for the load where it is issued).
+      auto tile_of = [&](int q) { // -1: past the end
+        const int cluster = first + W * (q / C), tile = cluster * C + q % C;
+        return q < 32 * C && cluster < n_clusters && tile < n_tiles ? tile : -1;
+      };
       float4 e0, e1, o0, o1;
       int e_rk = 0, o_rk = 0;
-      if (first < n_tiles)
-        load_cluster(first, e0, e1, e_rk);
+      if (tile_of(0) >= 0)
+        load_cluster(tile_of(0), e0, e1, e_rk);
 #pragma unroll 1
-      for (int tb = 0; tb < 32; tb += 2) {
-        const int tile = first + W * tb; // uniform
-        if (tile >= n_tiles)
+      for (int q = 0; q < 32 * C; q += 2) {
+        const int t_even = tile_of(q), t_odd = tile_of(q + 1), t_next = tile_of(q + 2); // uniform
+        if (t_even < 0)
           break;
-        const bool odd = tile + W < n_tiles;
-        if (odd)
-          load_cluster(tile + W, o0, o1, o_rk);
-        do_cluster(tb, tile, e0, e1, e_rk);
-        if (!odd)
+        if (t_odd >= 0)
+          load_cluster(t_odd, o0, o1, o_rk);
+        if (q % C == 0)
+          list_rays(q / C);
+        if (n_tot > 0)
+          do_tile(t_even, e0, e1, e_rk);
+        if (t_odd < 0)
           break;
-        if (tb + 2 < 32 && tile + 2 * W < n_tiles)
-          load_cluster(tile + 2 * W, e0, e1, e_rk);
-        do_cluster(tb + 1, tile + W, o0, o1, o_rk);
+        if (t_next >= 0)
+          load_cluster(t_next, e0, e1, e_rk);
+        if ((q + 1) % C == 0)
+          list_rays((q + 1) / C);
+        if (n_tot > 0)
+          do_tile(t_odd, o0, o1, o_rk);
       }
 #ifdef RT_PROFILE_PHASES
       RT_CSTAMP(tg2);

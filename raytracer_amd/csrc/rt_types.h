@@ -78,10 +78,17 @@ struct ShadeRec {      // 32 B per shape: what PathTracer needs from the hit sha
 constexpr int RT_TILE_WORDS = RT_TILE_BF16 ? 512 : 192;
 // From how many sphere tiles on a world's register spheres are ALSO kept as spatial clusters with bounding spheres, and the
 // tile kernel multiplies a tile only with the rays whose line meets its bound (rt_tile_cull.h)
+// Measured (Mrays/s, plain | culled; scripts/ab_cull.sh): 16 tiles (N=512) 14 176 | 12 267, 32 (N=1024) 8 022 | 9 943, 64 (N=2048) 4 365 | 7 160,
+// 128 (N=4096) 2 404 | 5 279.
 #ifndef RT_CULL_MIN_TILES
-#define RT_CULL_MIN_TILES 48
+#define RT_CULL_MIN_TILES 32
 #endif
-constexpr int RT_CULL_W = 4; // waves per workgroup of that kernel: cluster t belongs to wave t % RT_CULL_W
+constexpr int RT_CULL_W = 4; // waves per workgroup of that kernel: cluster j belongs to wave j % RT_CULL_W
+#ifndef RT_CULL_TILES
+#define RT_CULL_TILES 1
+#endif
+constexpr int RT_CULL_C = RT_CULL_TILES; // tiles per cluster (a power of two): cluster j = tiles C j ... C j + C - 1.  Measured at N=4096: 1 -> 5165,
+                                         // 2 -> 4702, 4 -> 4039 Mrays/s: tighter bounds beat fewer lists
 
 struct Scene {
   // scan lists
@@ -98,8 +105,8 @@ struct Scene {
   //    a place past n_wide holds 0 0 0 and k = +inf (never hit)
   const float *wide_tiles; int32_t n_wide_tiles;
   // rt_tile_cull.h (worlds of RT_CULL_MIN_TILES tiles or more, bf16 build; else n_cull_tiles = 0): the same spheres regrouped into
-  // spatial clusters of 32 — tiles as above in cluster order; the clusters' bounding spheres as tiles of the same form, one tile
-  // per group of 32 RT_CULL_W clusters and wave: row i of tile g RT_CULL_W + w bounds cluster 32 RT_CULL_W g + RT_CULL_W i + w;
+  // spatial clusters of 32 RT_CULL_C — tiles as above in cluster order; the clusters' bounding spheres as tiles of the same form,
+  // one tile per group of 32 RT_CULL_W clusters and wave: row i of tile g RT_CULL_W + w bounds cluster 32 RT_CULL_W g + RT_CULL_W i + w;
   // cluster position -> position in wide_recs (-1: an empty place) and the inverse
   const float *cull_tiles; const float *cull_bounds; const int32_t *cull_rank; const int32_t *cull_pos; int32_t n_cull_tiles;
   int32_t spheres_all_iso;        // every top-level sphere is translation * uniform scaling

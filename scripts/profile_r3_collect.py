@@ -74,6 +74,7 @@ def main():
         print(open(os.path.join(DST, "a_bench_kernel_stats.csv")).read()[:1500])
         return
     summarise("n4096_share", "scripts/pmc_run.sh r3_n4096_share -- --steps 1 --warmup 1 --no-cpu-baseline --no-configs   (bench.py defaults: 4096 spheres, 1920x1080 AA=4, shares 0 and 1 of 16)")
+    summarise("n4096_share_scan_all", "scripts/pmc_run.sh r3_n4096_share_scan_all -- --steps 1 --warmup 1 --no-cpu-baseline --no-configs --scan-all-tiles   (the same shares, every ray against every tile: k_render_path_tile)")
     summarise("c3", "scripts/pmc_run.sh r3_c3 -- --steps 2 --warmup 1 ... --scene demo_path --width 1280 --height 960 --aa 2 --shares 1   (C3, path 10/3/5)")
     summarise("c4", "scripts/pmc_run.sh r3_c4 -- --steps 2 --warmup 1 ... --scene csg_example --shares 1   (C4: 1920x1080 AA=4, path 10/3/5)")
     summarise("n512", "scripts/pmc_run.sh r3_n512 -- --steps 1 --warmup 1 ... --spheres 512 --shares 1   (the whole N=512 1920x1080 AA=4 frame per launch)")
