@@ -103,3 +103,48 @@ def test_equal_distances_keep_the_first_object():
     assert np.array_equal(culled, full)
     # against the oracle: the filters may rank two DIFFERENT near-equal spheres differently (tests/test_hit_level.py prices that)
     assert (culled[..., 0] != want[..., 0]).mean() <= 0.005
+
+
+def test_world_with_csg_objects_runs_the_culled_kernel_with_the_evaluators():
+    """1536 random spheres around a lens (the intersection of two spheres) and a holed ball (a difference): the CSG = true build of the
+    culled kernel.  Same frame as scanning all tiles; first hits against the oracle."""
+    rng = np.random.default_rng(17)
+    b = SceneBuilder()
+
+    def mat(obj_id):
+        return b.material("diffuse", b.pigment_uniform((0.0, 0.0, 0.0)), b.pigment_uniform((obj_id, obj_id, obj_id)))
+
+    b.plane(compose(translation([0, 0, -2])), mat(1))
+    b.sphere(compose(scaling([50, 50, 50])), mat(2))
+    left = b.sphere(compose(translation([0.0, -0.25, 0.0]), scaling([0.6, 0.6, 0.6])), mat(3), norender=True)
+    right = b.sphere(compose(translation([0.0, 0.25, 0.0]), scaling([0.6, 0.6, 0.6])), mat(4), norender=True)
+    b.csg(left, right, "intersection")
+    ball = b.sphere(compose(translation([1.0, 1.5, 0.5]), scaling([0.7, 0.7, 0.7])), mat(5), norender=True)
+    hole = b.sphere(compose(translation([0.5, 1.5, 0.5]), scaling([0.5, 0.5, 0.5])), mat(6), norender=True)
+    b.csg(ball, hole, "difference")
+    for k in range(1536):
+        r = float(np.float32(rng.uniform(0.05, 0.15)))
+        c = [float(np.float32(x)) for x in rng.uniform([-2, -6, -2 + r], [8, 6, 2])]
+        b.sphere(compose(translation(c), scaling([r, r, r])), mat(7 + k))
+    b.set_camera("perspective", compose(translation([-3, 0, 0])), None, 1.0)
+    scene = b.build()
+    w, h = 192, 108
+    world = DeviceWorld(scene)
+    tr = GpuImageTracer(w, h, scene.camera, 1)
+    kw = dict(n_rays=1, roulette=5, max_depth=0, seq_number=3)
+    culled = tr.fire_all_rays(world, RenderMode("path", **kw))
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile_cull<")
+    full = tr.fire_all_rays(world, RenderMode("path", scan_all_tiles=True, **kw))
+    assert tr.last_stats.kernel.decode().startswith("k_render_path_tile<")
+    # and a real path frame (the streams go through the CSG surfaces too)
+    path_kw = dict(n_rays=3, roulette=2, max_depth=3, seq_number=9)
+    a = tr.fire_all_rays(world, RenderMode("path", **path_kw))
+    rays_a = int(tr.last_stats.rays)
+    c = tr.fire_all_rays(world, RenderMode("path", scan_all_tiles=True, **path_kw))
+    assert rays_a == int(tr.last_stats.rays) and np.array_equal(a, c)
+    world.close()
+    assert np.array_equal(culled, full)
+    want = O.render(scene, O.make_cfg(w, h, "path", spp_edge=1, rng_mode=abi.RT_RNG_PER_NODE_STREAMS, **kw))[0]
+    ids = culled[..., 0]
+    assert ((ids == 3) | (ids == 4)).sum() > 50 and ((ids == 5) | (ids == 6)).sum() > 50  # both CSG objects are in the picture
+    assert (ids != want[..., 0]).mean() <= 0.005
