@@ -3,10 +3,11 @@
 //
 // k_render_path_tile tests every queued ray against every sphere: 128 tile products per 32 rays at N = 4096, of which a ray's
 // line meets a sphere in a handful.  Here the host also keeps the register spheres as spatial CLUSTERS of 32 (a k-d split of
-// the centres, rt_scene.hip) with one bounding sphere per cluster, and an iteration of a workgroup runs per GROUP of 32 clusters:
-//   level 1  every wave multiplies its own rays with the group's 32 BOUNDS — the very products of the sphere filter, a bound is a
-//            sphere — and leaves per ray a 32-bit word in LDS: bit t set if the ray's line meets bound t with the far root beyond
-//            the ray's tmin (a cluster wholly behind the ray cannot hold its hit).
+// the centres, rt_scene.hip) with one bounding sphere per cluster, and an iteration of a workgroup runs per GROUP of 32 clusters per wave:
+//   level 1  every wave multiplies ALL the workgroup's rays with the bounds of ITS OWN 32 clusters of the group (the clusters are dealt
+//            to the waves round-robin) — the very products of the sphere filter, a bound is a sphere — and keeps per ray a 32-bit
+//            word in registers: bit i set if the ray's line meets the bound of the wave's i-th cluster with the far root beyond the
+//            ray's tmin (a cluster wholly behind the ray cannot hold its hit).  Nothing is exchanged between the waves.
 //   level 2  every wave takes its share of the group's clusters; per cluster it collects the rays of the WHOLE workgroup whose bit
 //            is set (one ballot per 64 rays, the slot numbers compacted into a byte list in LDS) and multiplies the cluster's tile
 //            with those rays only, 32 at a time — products, candidates and keys exactly as k_render_path_tile forms them.
@@ -16,8 +17,9 @@
 // carries the sphere's position in OBJECT order (Scene::cull_rank), so equal distances still resolve as the reference's `<`.
 // The bounds are inflated by more than the filter's rounding can move either level-1 decision (rt_scene.hip).
 //
-// Work per iteration of a 256-ray workgroup at N = 4096 (128 clusters, a ray meets 8 of them on average): 4 x 8 bound products
-// + 128 x about 1.2 blocks, against 128 x 8 before.
+// Work per iteration of a 256-ray workgroup at N = 4096 (128 clusters, a ray meets 4.6 of them on average): 4 x 8 bound products
+// + 115 blocks of on average 10 rays, against 128 x 8 full blocks before; measured 2 404 -> 5 279 Mrays/s (DESIGN.md 4.4b has
+// the counters, what bounds the kernel now, and what was tried and not kept).
 #pragma once
 #include "rt_tile.h"
 
