@@ -536,6 +536,26 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
           std::memcpy(&tile[(c * 64 + half * 32 + i) * 4 + w], &word, 4);
         }
   };
+  // the same row for v_mfma_f32_16x16x32_bf16 (rt_tile_cull.h, level 2): the tile as two halves of 16 rows, lane l of half h holds the
+  // K slots 8 (l / 16) ... + 7 of row 16 h + l % 16 as four words
+  auto pack_tile_row16 = [&](float *tile, size_t i, const float v[4]) {
+    uint32_t parts[4][3];
+    for (int q = 0; q < 4; ++q)
+      split3(v[q], parts[q]);
+    uint32_t slot[32] = {0};
+    for (int q = 0; q < 3; ++q)
+      for (int j = 0; j < 6; ++j)
+        slot[6 * q + j] = parts[q][part_of_slot[j]];
+    slot[18] = slot[19] = slot[20] = 0x3f80u; // 1
+    slot[21] = parts[3][0], slot[22] = parts[3][1], slot[23] = parts[3][2];
+    const size_t h = i / 16, r = i % 16;
+    for (size_t kq = 0; kq < 4; ++kq)
+      for (size_t w = 0; w < 4; ++w) {
+        const size_t s0 = 8 * kq + 2 * w;
+        const uint32_t word = slot[s0] | (slot[s0 + 1] << 16);
+        std::memcpy(&tile[(h * 64 + kq * 16 + r) * 4 + w], &word, 4);
+      }
+  };
   static const float never_hit[4] = {0.f, 0.f, 0.f, 1e30f}; // a place past the last sphere: c = 1e30
   for (size_t t = 0; t < n_wide_tiles; ++t)
     for (size_t i = 0; i < 32; ++i) {
@@ -590,12 +610,12 @@ rt_status rt_scene_create(const rt_scene_desc *d, int device, rt_scene **out) {
       for (size_t i = 0; i < 32; ++i) {
         const size_t pos = t * 32 + i;
         if (pos >= n) {
-          pack_tile_row(&cull_tiles[t * rtd::RT_TILE_WORDS], i, never_hit);
+          pack_tile_row16(&cull_tiles[t * rtd::RT_TILE_WORDS], i, never_hit);
           continue;
         }
         const size_t k = static_cast<size_t>(order[pos]);
         cull_rank[pos] = static_cast<int32_t>(k), cull_pos[k] = static_cast<int32_t>(pos);
-        pack_tile_row(&cull_tiles[t * rtd::RT_TILE_WORDS], i, &wide_iso[4 * k]);
+        pack_tile_row16(&cull_tiles[t * rtd::RT_TILE_WORDS], i, &wide_iso[4 * k]);
       }
     for (size_t j = 0; j < n_clusters; ++j) {
       const size_t begin = j * CS, end = std::min(begin + CS, n);

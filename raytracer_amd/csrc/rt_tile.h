@@ -43,6 +43,7 @@ namespace rtd {
 // SIMD, where the VALU filter issued its 8 instructions per test at 3.9 cycles each instead of 2.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS image of one queued ray: quad 0 is read by lanes 0-31 (k = 0 of every product), quad 1 by lanes 32-63 (k = 1),
 // quad 2 by both.

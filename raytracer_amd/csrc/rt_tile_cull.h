@@ -10,7 +10,8 @@
 //            ray's tmin (a cluster wholly behind the ray cannot hold its hit).  Nothing is exchanged between the waves.
 //   level 2  every wave takes its share of the group's clusters; per cluster it collects the rays of the WHOLE workgroup whose bit
 //            is set (one ballot per 64 rays, the slot numbers compacted into a byte list in LDS) and multiplies the cluster's tile
-//            with those rays only, 32 at a time — products, candidates and keys exactly as k_render_path_tile forms them.
+//            with those rays only, 16 at a time (v_mfma_f32_16x16x32_bf16: a cluster meets 9 rays of a workgroup on average) — the
+//            same K slots, hence the same sums, candidates and keys as k_render_path_tile forms them.
 // The result is the same: a ray whose line misses a cluster's bound misses its spheres, a product element does not depend on
 // which other rays share its block, so every (ray, sphere) pair that could give a candidate is evaluated with the same bits and
 // the keys' minimum is the same — the frames are bit-identical to the unculled kernel's (tests/test_tile_cull.py).  A key
@@ -18,8 +19,8 @@
 // The bounds are inflated by more than the filter's rounding can move either level-1 decision (rt_scene.hip).
 //
 // Work per iteration of a 256-ray workgroup at N = 4096 (128 clusters, a ray meets 4.6 of them on average): 4 x 8 bound products
-// + 115 blocks of on average 10 rays, against 128 x 8 full blocks before; measured 2 404 -> 5 279 Mrays/s (DESIGN.md 4.4b has
-// the counters, what bounds the kernel now, and what was tried and not kept).
+// + 115 lists of on average 9 rays (16-ray blocks), against 128 x 8 full 32-ray blocks before; measured 2 449 -> 5 589 Mrays/s
+// (DESIGN.md 4.4b has the counters, what bounds the kernel now, and what was tried and not kept).
 #pragma once
 #include "rt_tile.h"
 
@@ -193,57 +194,72 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
         n_pairs += n_tot, n_blocks += (n_tot + 31) / 32, n_lists += 1;
 #endif
       };
-      // one tile (operand words a0 | a1, rk: its rows' positions in object order) against the listed rays
+      // One tile against the listed rays, 16 rays at a time on v_mfma_f32_16x16x32_bf16: K = 32 holds all 24 slots of a product, so a
+      // block of 16 rays x 32 spheres is four MFMAs of 16 cycles (two products x two halves of the tile) and 8 values of d per lane —
+      // half the matrix cycles, half the vector work and 3 instead of 5 operand reads per lane of what a 32-ray block costs, and
+      // most clusters meet fewer than 16 rays of a workgroup.  a0 | a1: the operand words of the tile's rows 0-15 | 16-31 (lane l: row
+      // l % 16, K slots 8 (l / 16) ... + 7, rt_scene.hip); lane l is ray l % 16 of the block and receives rows 4 (l / 16) + 0..3 of
+      // each half.  rk: the rows' positions in object order.
       auto do_tile = [&](int tile, const float4 &a0, const float4 &a1, int rk) {
+        union Op {
+          bf16x8 v;
+          float f[4];
+        };
+        auto op = [](const float4 &q) {
+          Op o;
+          o.f[0] = q.x, o.f[1] = q.y, o.f[2] = q.z, o.f[3] = q.w;
+          return o.v;
+        };
         if (half == 0)
           q_rank[wave][col] = rk;
         wave_sync();
+        const int ray16 = lane & 15, kq = lane >> 4, kb = kq < 3 ? kq : 0; // K slots 24-31 are zero on the sphere side: any finite words do
 #pragma unroll 1
-        for (int r0 = 0; r0 < n_tot; r0 += 32) {
-          const bool valid = r0 + col < n_tot;
-          const int slot = q_list[wave][valid ? r0 + col : 0];
-          const RayBlock rb = load_block(slot);
-          const float oo = valid ? rb.qc.x : INF_F; // a lane past the list's end asks d > +inf
-          const float tmin_u = rb.qc.y, inv_len = rb.qc.z;
-          const int self = __float_as_int(rb.qc.w);
-          f32x16 b, c;
-          tile_products_bf16(a0, a1, rb.qb0, rb.qb1, rb.qc0, rb.qc1, b, c);
-          float d[16];
+        for (int r0 = 0; r0 < n_tot; r0 += 16) {
+          const bool valid = r0 + ray16 < n_tot;
+          const int slot = q_list[wave][valid ? r0 + ray16 : 0];
+          const float4 *quads = ray_quads + 8 * slot;
+          const int sw = (slot >> 1) & 7;
+          const float4 qb = quads[kb ^ sw], qcq = quads[(3 + kb) ^ sw], own = quads[6 ^ sw];
+          const float oo = valid ? own.x : INF_F; // a lane past the list's end asks d > +inf
+          const float tmin_u = own.y, inv_len = own.z;
+          const int self = __float_as_int(own.w);
+          f32x4 b[2], c[2];
+          b[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op(a0), op(qb), f32x4{0}, 0, 0, 0);
+          c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op(a0), op(qcq), f32x4{0}, 0, 0, 0);
+          b[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op(a1), op(qb), f32x4{0}, 0, 0, 0);
+          c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op(a1), op(qcq), f32x4{0}, 0, 0, 0);
+          float d[2][4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            d[r] = fmaf(b[r], b[r], -c[r]);
-          float gmax[5];
+          for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int q = 0; q < 5; ++q)
-            gmax[q] = fmaxf(fmaxf(d[3 * q], d[3 * q + 1]), d[3 * q + 2]);
-          const float m = fmaxf(fmaxf(fmaxf(gmax[0], gmax[1]), gmax[2]), fmaxf(fmaxf(gmax[3], gmax[4]), d[15]));
-          if (m > oo) { // this ray's line meets one of the cluster's spheres
+            for (int r = 0; r < 4; ++r)
+              d[h][r] = fmaf(b[h][r], b[h][r], -c[h][r]);
+          const float g0 = fmaxf(fmaxf(d[0][0], d[0][1]), fmaxf(d[0][2], d[0][3])), g1 = fmaxf(fmaxf(d[1][0], d[1][1]), fmaxf(d[1][2], d[1][3]));
+          if (fmaxf(g0, g1) > oo) { // this ray's line meets one of the cluster's spheres
             unsigned long long best = ~0ull;
-            const int base = tile * 32 + 4 * half; // cluster position of this lane's row 0
+            const int base = tile * 32 + 4 * kq; // cluster position of this lane's row 0
             const int self_rel = self - base;
-            auto candidate = [&](int r) {
-              if (d[r] > oo) {
-                const int row = 8 * (r >> 2) + (r & 3); // a literal
+            auto candidate = [&](int h, int r) {
+              if (d[h][r] > oo) {
+                const int row = 16 * h + r; // a literal
                 // front root as a distance (the reference's rule: t1 unless it is below tmin, then t2 if beyond tmin)
-                const float sq = __builtin_amdgcn_sqrtf(d[r] - oo);
-                const float u1 = -b[r] - sq, u2 = -b[r] + sq;
+                const float sq = __builtin_amdgcn_sqrtf(d[h][r] - oo);
+                const float u1 = -b[h][r] - sq, u2 = -b[h][r] + sq;
                 const float u = u1 < tmin_u ? u2 : u1;
                 if (u > tmin_u && self_rel != row) {
                   // within a cluster the rows ascend with the object index (rt_scene.hip): equal t resolve as the reference's strict `<`
-                  const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(4 * half + row);
+                  const unsigned long long key = ((unsigned long long)__float_as_uint(u * inv_len) << 32) | (unsigned)(4 * kq + row);
                   best = min(best, key);
                 }
               }
             };
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-              if (gmax[q] > oo) {
-                candidate(3 * q);
-                candidate(3 * q + 1);
-                candidate(3 * q + 2);
-              }
+            if (g0 > oo) {
+              candidate(0, 0), candidate(0, 1), candidate(0, 2), candidate(0, 3);
             }
-            candidate(15);
+            if (g1 > oo) {
+              candidate(1, 0), candidate(1, 1), candidate(1, 2), candidate(1, 3);
+            }
             if (best != ~0ull) {
               // across clusters the key carries the sphere's position in OBJECT order
               const unsigned rank = static_cast<unsigned>(q_rank[wave][(unsigned)best & 31u]);
