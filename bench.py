@@ -180,8 +180,8 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
                "frac_algorithmic": alg / FP32_VALU_PEAK_TFLOPS, "algorithmic_peak_kind": "fp32 vector peak, 157.3 TFLOP/s",
                "algorithmic_flops_per_ray": algorithmic, "algorithmic_tflops": alg,
                "traffic": None, "traffic_source": None, "kernel": kernel, "rays_per_launch": rays, "kernel_ms": kernel_ms,
-               "note": "this kernel skips the tile products whose outcome is known (a ray's line misses the cluster's bounding sphere): 19 of 128 per 32 rays are "
-                       "left on the headline world, the frame is bit-identical (share0_sha256), the time per ray halves.  What is left is list building, "
+               "note": "this kernel skips the tile products whose outcome is known (a ray's line misses the cluster's bounding sphere): the equivalent of "
+                       "`mfma.tile_products_per_32_rays` of 128 are left on the headline world, the frame is bit-identical (share0_sha256), the time per ray more than halves.  What is left is list building, "
                        "LDS gathers and candidate handling - vector-ALU ISSUE work, few flops: `frac` (fp32 flops executed / fp32 peak) is small by nature, "
                        "`valu_issue.frac` says how full the issue slots are, `mfma.frac` how busy the matrix pipe is.  The kernel that does ALL the tile "
                        "products and sits on the matrix-pipe roofline is the sub-record N4096-share-scan-all (RT_FLAG_SCAN_ALL_TILES)."}
@@ -196,12 +196,15 @@ def roofline_block(census, kernel, rays, kernel_ms, profile=None, bvh=False):
                 out["frac"] = out["frac_executed"] = out["achieved"] / FP32_VALU_PEAK_TFLOPS
                 out["valu_fp32_flops_per_ray"] = flops
                 out["mean_active_lanes"] = lanes
-            if "SQ_INSTS_VALU_MFMA_BF16" in c:
-                per_ray = c["SQ_INSTS_VALU_MFMA_BF16"] / n
-                tf = rays * per_ray * 32768.0 / secs / 1e12
+            if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in c:
+                # the kernel mixes two shapes (bounds: 32x32x16 = 32768 flops; cluster tiles: 16x16x32 = 16384), so the flops come from the
+                # MOPS counter: 512 flops per counted op (64 per 32x32x16 MFMA — profiles/r3/n4096_share_scan_all_pmc.json: 16.0 MFMAs and 1024 ops per ray)
+                mfma_flops = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / n * 512.0
+                tf = rays * mfma_flops / secs / 1e12
                 n_tiles = -(-max(census["spheres"] - 1, 0) // 32)
-                out["mfma"] = {"achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "frac": tf / BF16_MFMA_PEAK_TFLOPS, "mfma_instr_per_ray": per_ray,
-                               "tile_products_per_32_rays": per_ray * 32.0 / 4.0, "scan_all_tile_products_per_32_rays": float(n_tiles)}
+                out["mfma"] = {"achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "frac": tf / BF16_MFMA_PEAK_TFLOPS,
+                               "mfma_instr_per_ray": c.get("SQ_INSTS_VALU_MFMA_BF16", 0.0) / n, "mfma_flops_per_ray": mfma_flops,
+                               "tile_products_per_32_rays": mfma_flops * 32.0 / (4.0 * 32768.0), "scan_all_tile_products_per_32_rays": float(n_tiles)}
             vi = valu_issue_block(profile, rays, kernel_ms)
             if vi:
                 out["valu_issue"] = vi
