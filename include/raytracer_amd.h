@@ -195,7 +195,7 @@ typedef struct rt_render_cfg {
    * of 32 spheres (k_render_path_tile), as smaller worlds always do.  By default such worlds keep their spheres as spatial
    * clusters of 32 with a bounding sphere each and multiply a tile only with the rays whose line meets its bound
    * (k_render_path_tile_cull): the same products for every pair that can give a hit, hence the same frame bit for bit, in
-   * about half the time at 4096 spheres.  For measurement: the kernel whose work does not depend on where the spheres are.
+   * less than half the time at 4096 spheres.  For measurement: the kernel whose work does not depend on where the spheres are.
    */
   uint32_t flags;
 } rt_render_cfg;
