@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
         }
         n_tot = __builtin_amdgcn_readfirstlane(n_tot);
 #ifdef RT_PROFILE_PHASES
-        n_pairs += n_tot, n_blocks += (n_tot + 31) / 32, n_lists += 1;
+        n_pairs += n_tot, n_blocks += (n_tot + 15) / 16, n_lists += 1;
 #endif
       };
       // One tile against the listed rays, 16 rays at a time on v_mfma_f32_16x16x32_bf16: K = 32 holds all 24 slots of a product, so a
