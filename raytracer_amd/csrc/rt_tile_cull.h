@@ -179,17 +179,25 @@ __global__ void __launch_bounds__(64 * W, RT_TILE_OCC) k_render_path_tile_cull(S
       // the rays of the workgroup that meet the bound of the wave's i-th cluster, listed in q_list[wave]
       auto list_rays = [&](int tb) {
         wave_sync(); // the list may still be read
-        n_tot = 0;
+        // all four ballots first, then the offsets (scalar), then the stores: the four chains run side by side
+        unsigned long long bal[W];
+        bool meets[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-          const bool meets = (mw[w] >> tb) & 1u;
-          const unsigned long long bal = __ballot(meets);
-          if (meets)
-            q_list[wave][n_tot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
-                static_cast<uint8_t>(64 * w + lane);
-          n_tot += __popcll(bal);
+          meets[w] = (mw[w] >> tb) & 1u;
+          bal[w] = __ballot(meets[w]);
         }
-        n_tot = __builtin_amdgcn_readfirstlane(n_tot);
+        int off[W + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          off[w + 1] = off[w] + __popcll(bal[w]);
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          if (meets[w])
+            q_list[wave][off[w] + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[w] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[w], 0u))] =
+                static_cast<uint8_t>(64 * w + lane);
+        n_tot = __builtin_amdgcn_readfirstlane(off[W]);
 #ifdef RT_PROFILE_PHASES
         n_pairs += n_tot, n_blocks += (n_tot + 15) / 16, n_lists += 1;
 #endif
